@@ -1,0 +1,208 @@
+"""Shared test helpers: fixtures, ctypes bindings to the CPU oracle (oracle/liboracle.so) and, when it was
+built in the container that has the upstream tree, to the compiled reference (oracle/_ref/libldpc_ref.so).
+
+Everything here is test infrastructure; the product (ldpc-lib_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+# decoders.h:16-28 enum DEC_ID
+BP_DEC, SP_DEC, ASP_DEC, MS_DEC, IMS_DEC, IASP_DEC, FHT_DEC, TASP_DEC, LMS_DEC, LCHE_DEC = range(10)
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_short_p = C.POINTER(C.c_short)
+
+
+def load_base_matrix():
+    """the 16x32 base matrix the reference's own `search` produced (shifts mod 126)."""
+    return np.loadtxt(os.path.join(GOLDEN_DIR, "h16x32_m126.txt"), dtype=np.int32)
+
+
+def relift(H, M):
+    """main_simulation.cpp:400-414: entries > 0 become entry % M; in column rows-1 a result of 0 becomes 1."""
+    H = np.array(H, dtype=np.int32, copy=True)
+    rows = H.shape[0]
+    for i in range(H.shape[0]):
+        for j in range(H.shape[1]):
+            if H[i, j] > 0:
+                t = int(H[i, j]) % M
+                if j == rows - 1 and t == 0:
+                    t = 1
+                H[i, j] = t
+    return H
+
+
+def _as_double_p(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+class SimResult(C.Structure):
+    _fields_ = [("ber", C.c_double), ("fer", C.c_double), ("nse", C.c_longlong), ("nde", C.c_longlong),
+                ("nue", C.c_longlong), ("experiment", C.c_longlong), ("sum_abs_iter", C.c_longlong),
+                ("rng_next", C.c_uint)]
+
+
+_oracle_lib = None
+
+
+def oracle_lib():
+    """Load (building on demand with plain gcc/g++) the CPU restatement."""
+    global _oracle_lib
+    if _oracle_lib is not None:
+        return _oracle_lib
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ldpc_oracle.c", "ldpc_oracle.h", "harness_oracle.cpp", "harness_oracle.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
+    lib = C.CDLL(so)
+    lib.orc_open.restype = C.c_void_p
+    lib.orc_open.argtypes = [C.c_int, C.c_int, C.c_int, c_short_p]
+    lib.orc_close.argtypes = [C.c_void_p]
+    lib.orc_n.argtypes = [C.c_void_p]
+    lib.orc_min_sum.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int, C.c_double]
+    lib.orc_lmin_sum.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int]
+    lib.orc_sum_prod.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int]
+    lib.orc_imin_sum.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
+    lib.orc_syndrome_nonzero.argtypes = [C.c_void_p, c_double_p]
+    lib.orc_qam_modulate.argtypes = [C.c_int, c_double_p, C.c_int, c_double_p]
+    lib.orc_qam_demodulate.argtypes = [C.c_int, C.c_double, C.c_double, c_double_p, C.c_int, c_double_p, C.c_int]
+    lib.orc_bp_simulation.argtypes = [C.c_int, C.c_int, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                      C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint, C.POINTER(SimResult), c_int_p]
+    lib.orc_rng_gaussians.argtypes = [C.c_uint, C.c_int, c_double_p, C.c_int]
+    lib.orc_awgn_llr.argtypes = [C.c_uint, C.c_int, C.c_double, C.c_double, c_double_p, C.c_int]
+    _oracle_lib = lib
+    return lib
+
+
+def ref_lib():
+    """The compiled upstream reference (only exists where oracle/Makefile's `ref` target was run). None if absent."""
+    so = os.path.join(ORACLE_DIR, "_ref", "libldpc_ref.so")
+    if not os.path.exists(so):
+        return None
+    lib = C.CDLL(so)
+    lib.ref_open.restype = C.c_void_p
+    lib.ref_open.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, c_short_p]
+    lib.ref_close.argtypes = [C.c_void_p]
+    lib.ref_decode.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, C.c_int, C.c_int]
+    lib.ref_qam_modulate.argtypes = [C.c_int, c_double_p, C.c_int, c_double_p]
+    lib.ref_qam_demodulate.argtypes = [C.c_int, C.c_double, C.c_double, c_double_p, C.c_int, c_double_p, C.c_int]
+    return lib
+
+
+class _Decoder:
+    """Common batch front end: decode(llr[B,N]) -> (decword[B,N] float64, iters[B] int32, llr_after[B,N])."""
+
+    def decode(self, dec_id, llr, maxiter, decision=0):
+        llr = np.ascontiguousarray(llr, dtype=np.float64)
+        single = llr.ndim == 1
+        if single:
+            llr = llr[None, :]
+        B, N = llr.shape
+        assert N == self.N
+        dec = np.empty((B, N), dtype=np.float64)
+        its = np.empty(B, dtype=np.int32)
+        after = llr.copy()
+        for b in range(B):
+            its[b] = self._one(dec_id, after[b], dec[b], maxiter, decision)
+        if single:
+            return dec[0], int(its[0]), after[0]
+        return dec, its, after
+
+
+class Oracle(_Decoder):
+    def __init__(self, H, M):
+        self.lib = oracle_lib()
+        H = np.ascontiguousarray(H, dtype=np.int16)
+        self.rh, self.nh = H.shape
+        self.M = M
+        self.N = self.nh * M
+        self.R = self.rh * M
+        self.h = self.lib.orc_open(self.rh, self.nh, M, H.ctypes.data_as(c_short_p))
+        assert self.h
+
+    def close(self):
+        if self.h:
+            self.lib.orc_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _one(self, dec_id, y, dec, maxiter, decision):
+        yp, dp = _as_double_p(y), _as_double_p(dec)
+        if dec_id == MS_DEC:
+            return self.lib.orc_min_sum(self.h, yp, dp, maxiter, decision, 0.8)
+        if dec_id == LMS_DEC:
+            return self.lib.orc_lmin_sum(self.h, yp, dp, maxiter, decision)
+        if dec_id == SP_DEC:
+            return self.lib.orc_sum_prod(self.h, yp, dp, maxiter, decision)
+        if dec_id == IMS_DEC:
+            return self.lib.orc_imin_sum(self.h, yp, dp, maxiter, decision, 0.8, 1.4, 6, 8)
+        raise ValueError(dec_id)
+
+
+class Reference(_Decoder):
+    """The compiled upstream decoders (oracle/_ref). Construct only when ref_lib() is not None."""
+
+    def __init__(self, dec_id, H, M):
+        self.lib = ref_lib()
+        assert self.lib is not None
+        H = np.ascontiguousarray(H, dtype=np.int16)
+        self.rh, self.nh = H.shape
+        self.M = M
+        self.N = self.nh * M
+        self.dec_id = dec_id
+        self.h = self.lib.ref_open(dec_id, self.rh, self.nh, M, H.ctypes.data_as(c_short_p))
+        assert self.h
+
+    def close(self):
+        if self.h:
+            self.lib.ref_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _one(self, dec_id, y, dec, maxiter, decision):
+        assert dec_id == self.dec_id
+        return self.lib.ref_decode(self.h, dec_id, _as_double_p(y), _as_double_p(dec), maxiter, decision)
+
+
+def code_rate(H):
+    rh, nh = H.shape
+    return (nh - rh) / nh
+
+
+def awgn_llr(H, M, snr_db, seed, frames, burn_codeword=True):
+    """LLRs in the reference's draw order (bp_simulation.cpp:512,600-605): one mt19937 stream, the
+    (nh-rh)*M next_random_int draws of random_codeword() first, then frames*N Gaussians."""
+    lib = oracle_lib()
+    rh, nh = H.shape
+    N = nh * M
+    out = np.empty(frames * N, dtype=np.float64)
+    lib.orc_awgn_llr(seed, (nh - rh) * M if burn_codeword else 0, snr_db, code_rate(H), _as_double_p(out), frames * N)
+    return out.reshape(frames, N)
+
+
+def pack_bits(dec):
+    """decword (0.0/1.0 doubles, [B,N]) -> little-endian packed uint32 words [B, ceil(N/32)] (bit i of word w = variable 32*w+i)."""
+    dec = np.asarray(dec)
+    B, N = dec.shape
+    W = (N + 31) // 32
+    bits = np.zeros((B, W * 32), dtype=np.uint8)
+    bits[:, :N] = dec != 0
+    return np.packbits(bits.reshape(B, W, 32), axis=2, bitorder="little").view(np.uint32).reshape(B, W)

@@ -1,0 +1,50 @@
+"""CPU: the C restatement (oracle/) reproduces every golden vector that oracle/make_goldens.py produced from the
+compiled upstream reference -- hard bits, signed iteration counts and a-posteriori soft values, bit for bit."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from ldpc_testlib import GOLDEN_DIR, SP_DEC, Oracle, oracle_lib, pack_bits, _as_double_p
+
+DECODER_SETS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                      if not os.path.basename(p).startswith("qam"))
+
+
+def test_golden_sets_present():
+    assert len(DECODER_SETS) >= 12
+    assert os.path.exists(os.path.join(GOLDEN_DIR, "qam_frontend.npz"))
+
+
+@pytest.mark.parametrize("name", DECODER_SETS)
+def test_oracle_matches_reference_golden(name):
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    H, M, dec_id, maxiter = g["H"], int(g["M"]), int(g["dec_id"]), int(g["maxiter"])
+    o = Oracle(H, M)
+    dec, its, _ = o.decode(dec_id, g["llr"], maxiter, 0)
+    assert np.array_equal(its, g["iters"])
+    assert np.array_equal(pack_bits(dec), g["hard"])
+    nsoft = g["soft"].shape[0]
+    soft, its1, _ = o.decode(dec_id, g["llr"][:nsoft], maxiter, 1)
+    assert np.array_equal(its1, g["iters"][:nsoft])
+    # same libm on both sides in this container, so even sum-product is bit-identical here
+    assert np.array_equal(soft, g["soft"], equal_nan=True)
+
+
+def test_qam_frontend_matches_reference_golden():
+    g = np.load(os.path.join(GOLDEN_DIR, "qam_frontend.npz"))
+    lib = oracle_lib()
+    for Q, m in ((4, 2), (16, 4)):
+        bits = np.ascontiguousarray(g[f"q{Q}_bits"])
+        sym = np.zeros(2 * (bits.size // m))
+        ns = lib.orc_qam_modulate(Q, _as_double_p(bits), bits.size, _as_double_p(sym))
+        assert ns == bits.size // m
+        assert np.array_equal(sym, g[f"q{Q}_sym"])
+        for out_type in (0, 1):
+            for s in ("0p35", "0p8", "2p5"):
+                key = f"q{Q}_t{out_type}_s{s}"
+                x = np.ascontiguousarray(g[key + "_x"])
+                llr = np.zeros(ns * m)
+                lib.orc_qam_demodulate(Q, 26.0, float(s.replace("p", ".")), _as_double_p(x), ns, _as_double_p(llr), out_type)
+                assert np.array_equal(llr, g[key + "_llr"], equal_nan=True), key

@@ -1,0 +1,40 @@
+"""CPU, build container only: the C restatement against the compiled upstream reference (oracle/_ref) on fresh
+random batches beyond the committed goldens.  Skipped wherever oracle/_ref was not built."""
+import numpy as np
+import pytest
+
+from ldpc_testlib import (IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, Oracle, Reference, awgn_llr, load_base_matrix, ref_lib,
+                          relift)
+
+pytestmark = pytest.mark.skipif(ref_lib() is None, reason="oracle/_ref not built (needs the upstream tree)")
+
+
+@pytest.mark.parametrize("dec_id,M,snr,frames,maxiter,seed", [
+    (MS_DEC, 64, 1.5, 60, 50, 11), (MS_DEC, 64, 2.5, 60, 10, 12), (MS_DEC, 7, 3.0, 60, 30, 13),
+    (MS_DEC, 126, 1.7, 12, 50, 14), (LMS_DEC, 64, 1.2, 40, 50, 15), (LMS_DEC, 200, 1.4, 8, 50, 16),
+    (SP_DEC, 64, 1.5, 40, 50, 17), (SP_DEC, 33, 2.0, 30, 25, 18), (IMS_DEC, 64, 2.2, 30, 50, 19),
+])
+def test_restatement_equals_compiled_reference(dec_id, M, snr, frames, maxiter, seed):
+    H = relift(load_base_matrix(), M)
+    llr = awgn_llr(H, M, snr, seed, frames)
+    llr[0, :5] = [0.0, -0.0, 25.0, -25.0, 1e-300]  # zeros, clamp range (SP INPUT_LIMIT 20), denormal-ish
+    o, r = Oracle(H, M), Reference(dec_id, H, M)
+    for decision in (0, 1):
+        d1, i1, a1 = o.decode(dec_id, llr, maxiter, decision)
+        d2, i2, a2 = r.decode(dec_id, llr, maxiter, decision)
+        assert np.array_equal(i1, i2)
+        assert np.array_equal(d1, d2, equal_nan=True)
+        assert np.array_equal(a1, a2, equal_nan=True)  # SP clobbers its input identically
+
+
+def test_irregular_small_matrix():
+    # hand-made 3x6 base matrix with an empty-heavy row, a weight-1 column and shift == M-1
+    H = np.array([[0, -1, 3, -1, 2, 0], [4, 1, -1, 0, -1, -1], [-1, 2, 0, 4, 4, 1]], dtype=np.int16)
+    M = 5
+    rng = np.random.RandomState(3)
+    llr = rng.randn(50, 6 * M) * 2.0 + 1.0
+    for dec_id in (MS_DEC, LMS_DEC, SP_DEC):
+        o, r = Oracle(H, M), Reference(dec_id, H, M)
+        d1, i1, _ = o.decode(dec_id, llr, 30, 0)
+        d2, i2, _ = r.decode(dec_id, llr, 30, 0)
+        assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
