@@ -1,0 +1,230 @@
+"""ctypes binding of the C-ABI in include/ldpc_hip.h (what cgo / JNI / any FFI would bind the same way).
+
+Device buffers are torch CUDA tensors (torch = allocator + streams only); host entry points take numpy arrays laid
+out exactly like the upstream per-frame arrays.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+# decoders.h:16-28 enum DEC_ID
+DEC_SP, DEC_MS, DEC_IMS, DEC_LMS = 1, 3, 4, 8
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG_DIR)
+_LIB_NAME = "libldpc_hip.so"
+_lib = None
+
+
+class LdpcHipError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_PKG_DIR, _LIB_NAME)
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into ldpc-lib_amd/libldpc_hip.so (in-tree, so it travels with the repo snapshot).
+    -ffp-contract=off is part of the numerics contract: `y + s*alpha` must stay two roundings (decoders.cpp:4682)."""
+    src_dir = os.path.join(_PKG_DIR, "csrc")
+    srcs = [os.path.join(src_dir, "ldpc_hip.hip")]
+    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir)] + [os.path.join(_ROOT, "include", "ldpc_hip.h")]
+    out = library_path()
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-I", os.path.join(_ROOT, "include"), *srcs, "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
+def load_library():
+    """Load libldpc_hip.so.  Raises LdpcHipError when it is missing -- there is no other compute path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch ships its own ROCm runtime (libamdhip64).  Load torch FIRST so that this process has exactly one HIP
+    # runtime and our library binds to the same one that owns torch's allocations and streams; loading ours first
+    # pulls in /opt/rocm's copy and the second runtime then finds no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    path = library_path()
+    if not os.path.exists(path):
+        raise LdpcHipError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                           "There is no CPU fallback.")
+    lib = C.CDLL(path)
+    vp, i32, i64, f64, u64 = C.c_void_p, C.c_int, C.c_longlong, C.c_double, C.c_uint64
+    lib.ldpc_hip_abi_version.restype = i32
+    lib.ldpc_hip_last_error.restype = C.c_char_p
+    lib.ldpc_hip_device_count.restype = i32
+    lib.ldpc_hip_open.argtypes = [i32, i32, i32, i32, vp, i32, C.POINTER(vp)]
+    lib.ldpc_hip_close.argtypes = [vp]
+    lib.ldpc_hip_close.restype = None
+    for f in ("ldpc_hip_n", "ldpc_hip_r", "ldpc_hip_edges", "ldpc_hip_hard_words"):
+        getattr(lib, f).argtypes = [vp]
+    lib.ldpc_hip_decode_dev.argtypes = [vp, vp, i64, i32, f64, vp, vp, vp, vp]
+    lib.ldpc_hip_decode_host.argtypes = [vp, vp, i64, i32, i32, f64, vp, vp, i32]
+    lib.ldpc_hip_awgn_llr_dev.argtypes = [vp, f64, i32, i32, u64, i64, i64, vp, vp]
+    lib.ldpc_hip_awgn_qam16_llr_dev.argtypes = [vp, f64, f64, u64, i64, i64, vp, vp]
+    lib.ldpc_hip_qam_demod_dev.argtypes = [i32, f64, f64, vp, i64, vp, i32, i32, vp]
+    lib.ldpc_hip_count_errors_dev.argtypes = [vp, vp, vp, i64, vp, vp, vp]
+    lib.ldpc_hip_simulate.argtypes = [vp, f64, i32, i32, i32, f64, u64, i64, i64, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.ldpc_hip_profile_enable.argtypes = [vp, i32]
+    lib.ldpc_hip_profile_read.argtypes = [vp, C.POINTER(f64), C.POINTER(i64), i32]
+    if lib.ldpc_hip_abi_version() != 1:
+        raise LdpcHipError("libldpc_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise LdpcHipError(f"{what}: {lib.ldpc_hip_last_error().decode()} (code {rc})")
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(getattr(stream, "cuda_stream", stream))
+
+
+class LdpcHip:
+    """One opened code on one GPU == upstream's DEC_STATE (decod_open + hd fill + decod_init)."""
+
+    def __init__(self, decoder_id, H, M, device=0):
+        self.lib = load_library()
+        H = np.ascontiguousarray(H, dtype=np.int16)
+        self.rh, self.nh = H.shape
+        self.M, self.decoder_id, self.device = int(M), int(decoder_id), int(device)
+        h = C.c_void_p()
+        rc = self.lib.ldpc_hip_open(self.decoder_id, self.rh, self.nh, self.M, H.ctypes.data, self.device, C.byref(h))
+        _check(self.lib, rc, "ldpc_hip_open")
+        self.h = h
+        self.N = self.lib.ldpc_hip_n(h)
+        self.R = self.lib.ldpc_hip_r(h)
+        self.edges = self.lib.ldpc_hip_edges(h)
+        self.hard_words = self.lib.ldpc_hip_hard_words(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ldpc_hip_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- device-resident batch API -------------------------------------------------------------------
+    def _dev(self):
+        import torch
+        return torch.device("cuda", self.device)
+
+    def decode(self, llr, maxiter, alpha=0.8, want_hard=True, want_soft=False, stream=None, out=None):
+        """llr: torch float64 CUDA tensor [B,N] (not modified).  Returns (hard int32[B,W] | None, iters int32[B], soft | None).
+        hard holds the packed uint32 words reinterpreted as int32 (torch has no uint32 arithmetic)."""
+        import torch
+        assert llr.is_cuda and llr.dtype == torch.float64 and llr.is_contiguous() and llr.shape[-1] == self.N
+        B = llr.shape[0]
+        if out is not None:
+            hard, iters, soft = out
+        else:
+            hard = torch.empty((B, self.hard_words), dtype=torch.int32, device=llr.device) if want_hard else None
+            iters = torch.empty((B,), dtype=torch.int32, device=llr.device)
+            soft = torch.empty((B, self.N), dtype=torch.float64, device=llr.device) if want_soft else None
+        rc = self.lib.ldpc_hip_decode_dev(self.h, llr.data_ptr(), B, int(maxiter), float(alpha),
+                                          hard.data_ptr() if hard is not None else None, iters.data_ptr(),
+                                          soft.data_ptr() if soft is not None else None, _stream_ptr(stream))
+        _check(self.lib, rc, "ldpc_hip_decode_dev")
+        return hard, iters, soft
+
+    def awgn_llr(self, snr_db, seed, first_frame, B, modulation=0, punctured_blocks=0, out=None, stream=None, T=26.0):
+        """Device-side channel: modulation 0 BPSK, 1 QAM4 (upstream formulas), 2 16-QAM chain (as intended upstream)."""
+        import torch
+        llr = out if out is not None else torch.empty((B, self.N), dtype=torch.float64, device=self._dev())
+        if modulation == 2:
+            rc = self.lib.ldpc_hip_awgn_qam16_llr_dev(self.h, float(snr_db), float(T), int(seed), int(first_frame), int(B),
+                                                      llr.data_ptr(), _stream_ptr(stream))
+        else:
+            rc = self.lib.ldpc_hip_awgn_llr_dev(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(seed),
+                                                int(first_frame), int(B), llr.data_ptr(), _stream_ptr(stream))
+        _check(self.lib, rc, "ldpc_hip_awgn_llr_dev")
+        return llr
+
+    def count_errors(self, hard, iters, counters=None, want_frame_info=False, stream=None):
+        """counters: int64 CUDA tensor[5] accumulated in place: nse, nde, nue, frames, sum|iters| (bp_simulation.cpp:805-810)."""
+        import torch
+        B = iters.shape[0]
+        if counters is None:
+            counters = torch.zeros(5, dtype=torch.int64, device=iters.device)
+        info = torch.empty((B,), dtype=torch.int32, device=iters.device) if want_frame_info else None
+        rc = self.lib.ldpc_hip_count_errors_dev(self.h, hard.data_ptr(), iters.data_ptr(), B,
+                                                info.data_ptr() if info is not None else None, counters.data_ptr(),
+                                                _stream_ptr(stream))
+        _check(self.lib, rc, "ldpc_hip_count_errors_dev")
+        return counters, info
+
+    def simulate(self, snr_db, maxiter, seed, first_frame, B, modulation=0, punctured_blocks=0, alpha=0.8):
+        cnt = (C.c_ulonglong * 4)()
+        sit = C.c_ulonglong()
+        rc = self.lib.ldpc_hip_simulate(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(maxiter),
+                                        float(alpha), int(seed), int(first_frame), int(B), cnt, C.byref(sit))
+        _check(self.lib, rc, "ldpc_hip_simulate")
+        return {"nse": cnt[0], "nde": cnt[1], "nue": cnt[2], "frames": cnt[3], "sum_abs_iters": sit.value}
+
+    # ---- host-pointer API (upstream array layout, PCIe inclusive) --------------------------------------
+    def decode_host(self, llr, maxiter, decision=0, alpha=0.8, clobber_sp_input=True):
+        """llr: float64 [B,N] or [N].  Returns (decword, iters, llr_after) like the upstream decoder call: decword is
+        0.0/1.0 (decision 0) or the a-posteriori values (decision 1); llr_after is what upstream leaves in its input
+        array (unchanged for MS/LMS, the likelihood ratios for SP, decoders.cpp:1950,2124)."""
+        llr = np.array(llr, dtype=np.float64, order="C", copy=True)
+        single = llr.ndim == 1
+        if single:
+            llr = llr[None, :]
+        B = llr.shape[0]
+        assert llr.shape[1] == self.N
+        dec = np.empty((B, self.N), dtype=np.float64)
+        its = np.empty(B, dtype=np.int32)
+        rc = self.lib.ldpc_hip_decode_host(self.h, llr.ctypes.data, B, int(maxiter), int(decision), float(alpha),
+                                           dec.ctypes.data, its.ctypes.data, 1 if clobber_sp_input else 0)
+        _check(self.lib, rc, "ldpc_hip_decode_host")
+        if single:
+            return dec[0], int(its[0]), llr[0]
+        return dec, its, llr
+
+    # ---- kernel timing (HIP events on the launch stream) ------------------------------------------------
+    def profile(self, enable=True):
+        _check(self.lib, self.lib.ldpc_hip_profile_enable(self.h, 1 if enable else 0), "ldpc_hip_profile_enable")
+
+    def profile_read(self, reset=True):
+        ms, n = C.c_double(), C.c_longlong()
+        _check(self.lib, self.lib.ldpc_hip_profile_read(self.h, C.byref(ms), C.byref(n), 1 if reset else 0), "ldpc_hip_profile_read")
+        return ms.value, n.value
+
+
+def qam_demod(x, Q, T, sigma, out_type=0, device=0, stream=None):
+    """Function-level soft demapper (QAM_demodulator.cpp Demodulate) on a CUDA float64 tensor x[ns,2] -> [ns, log2 Q]."""
+    import torch
+    lib = load_library()
+    m = {4: 2, 16: 4}[Q]
+    ns = x.shape[0]
+    out = torch.empty((ns, m), dtype=torch.float64, device=x.device)
+    rc = lib.ldpc_hip_qam_demod_dev(Q, float(T), float(sigma), x.data_ptr(), ns, out.data_ptr(), out_type, device, _stream_ptr(stream))
+    _check(lib, rc, "ldpc_hip_qam_demod_dev")
+    return out

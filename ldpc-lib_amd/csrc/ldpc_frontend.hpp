@@ -1,0 +1,237 @@
+// ldpc_frontend.hpp -- channel front end and error accounting kernels around the decoders (gfx950).
+//
+//   awgn_llr_kernel        bp_simulation.cpp:444-449,600-612,697-710  (BPSK / QAM4 LLRs of the all-zero codeword)
+//   awgn_qam16_llr_kernel  QAM_modulator.cpp:142 + bp_simulation.cpp:621-628 (as intended) + QAM_demodulator.cpp:203-275
+//   qam_demod_kernel       QAM_demodulator.cpp:99-566 Demodulate(), Q in {4,16}
+//   count_errors_kernel    bp_simulation.cpp:731-759,805-810
+//
+// These are streaming, HBM-bound byte/word kernels: one element (pair) per lane, coalesced 8/16-byte accesses,
+// grid-stride loops; no LDS.  Noise comes from a counter-based Philox4x32-10 generator keyed by
+// (seed, global frame index, element index), so a frame's noise does not depend on how frames are batched or
+// sharded over GPUs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ldpc {
+
+// ---- Philox4x32-10 (Salmon et al., SC'11): public algorithm, restated here; the CPU twin is in tests/ ----
+struct Philox4 { uint32_t x[4]; };
+
+__host__ __device__ inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                 uint32_t k1) {
+    uint32_t c[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    Philox4 o;
+    o.x[0] = c[0]; o.x[1] = c[1]; o.x[2] = c[2]; o.x[3] = c[3];
+    return o;
+}
+
+// two 53-bit uniforms in (0,1) from one Philox block
+__host__ __device__ inline void philox_uniform2(const Philox4 &p, double &u1, double &u2) {
+    const uint64_t a = (((uint64_t)p.x[0] << 32) | p.x[1]) >> 11;
+    const uint64_t b = (((uint64_t)p.x[2] << 32) | p.x[3]) >> 11;
+    u1 = ((double)a + 0.5) * (1.0 / 9007199254740992.0);
+    u2 = ((double)b + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// Box-Muller pair for (frame, pair index) of stream `tag`
+__device__ __forceinline__ void gauss_pair(uint64_t seed, uint64_t frame, uint32_t pair, uint32_t tag, double &g0,
+                                           double &g1) {
+    const Philox4 p = philox4x32_10((uint32_t)frame, (uint32_t)(frame >> 32), pair, tag, (uint32_t)seed,
+                                    (uint32_t)(seed >> 32));
+    double u1, u2;
+    philox_uniform2(p, u1, u2);
+    const double rad = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    g0 = rad * c;
+    g1 = rad * s;
+}
+
+struct AwgnArgs {
+    double *llr;            // [B][N]
+    long long B, first_frame;
+    int N, punct_start;     // LLR index where the punctured tail begins (N when nothing is punctured)
+    double sigma;           // bp_simulation.cpp:445 (BPSK) or :449 (QAM4)
+    double punct_val;       // :700
+    uint64_t seed;
+};
+
+// llr = -2.0 * (sigma*g + 2.0*cw - 1.0) / (sigma*sigma), cw == 0   (bp_simulation.cpp:603 / :610)
+__global__ void __launch_bounds__(256) awgn_llr_kernel(const AwgnArgs a) {
+    const int pairs = (a.N + 1) >> 1;
+    const long long total = a.B * (long long)pairs;
+    const double s2 = a.sigma * a.sigma;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / pairs;
+        const int p = (int)(i - b * pairs);
+        double g0, g1;
+        gauss_pair(a.seed, (uint64_t)(a.first_frame + b), (uint32_t)p, 0u, g0, g1);
+        const int v = 2 * p;
+        double l0 = -2.0 * (a.sigma * g0 + 2.0 * 0.0 - 1.0) / s2;
+        double l1 = -2.0 * (a.sigma * g1 + 2.0 * 0.0 - 1.0) / s2;
+        if (v >= a.punct_start) l0 = a.punct_val;
+        if (v + 1 >= a.punct_start) l1 = a.punct_val;
+        double *row = a.llr + b * (long long)a.N;
+        if (v + 1 < a.N && ((a.N & 1) == 0)) {
+            *reinterpret_cast<double2 *>(row + v) = make_double2(l0, l1);  // 16-byte store, rows stay 16-B aligned
+        } else {
+            row[v] = l0;
+            if (v + 1 < a.N) row[v + 1] = l1;
+        }
+    }
+}
+
+// ---- soft demapper --------------------------------------------------------------------------------------
+// One PAM rail of a 16-QAM symbol: QAM_demodulator.cpp:171-275.  lattice = {-3,-1,1,3} (levels ordered 00 01 11 10).
+__device__ __forceinline__ double llr_or_p(double p0, double p1, double T, int out_type) {
+    if (p0 == 0.0) return out_type == 0 ? T : 1.0;
+    if (p1 == 0.0) return out_type == 0 ? -T : 0.0;
+    return out_type == 0 ? log(p1 / p0) : p1;
+}
+
+__device__ __forceinline__ void demod_rail16(double x, double N0, double T, int out_type, double &b0, double &b1) {
+    double P[4], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double t = x - (double)(2 * i - 3);
+        t *= t;
+        t /= N0;
+        P[i] = (t < T) ? exp(-t) : 0.0;
+        sum += P[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) P[i] /= sum;
+    b0 = llr_or_p(P[0] + P[1], P[2] + P[3], T, out_type);
+    b1 = llr_or_p(P[0] + P[3], P[1] + P[2], T, out_type);
+}
+
+struct DemodArgs {
+    const double *x;  // [ns][2]
+    double *out;      // [ns][m]
+    long long ns;
+    int Q, out_type;
+    double T, sigma;
+};
+
+__global__ void __launch_bounds__(256) qam_demod_kernel(const DemodArgs a) {
+    const double N0 = 2.0 * a.sigma * a.sigma;  // QAM_demodulator.cpp:142
+    for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < a.ns;
+         s += (long long)gridDim.x * blockDim.x) {
+        const double2 xy = *reinterpret_cast<const double2 *>(a.x + 2 * s);
+        if (a.Q == 4) {  // :113-139 (out_type 1 normalises over the whole block: done by the caller's second pass)
+            const double sigma2 = a.sigma * a.sigma;
+            a.out[2 * s] = 2.0 * xy.x / sigma2;
+            a.out[2 * s + 1] = 2.0 * xy.y / sigma2;
+        } else {
+            double b0, b1, b2, b3;
+            demod_rail16(xy.x, N0, a.T, a.out_type, b0, b1);
+            demod_rail16(xy.y, N0, a.T, a.out_type, b2, b3);
+            *reinterpret_cast<double2 *>(a.out + 4 * s) = make_double2(b0, b1);
+            *reinterpret_cast<double2 *>(a.out + 4 * s + 2) = make_double2(b2, b3);
+        }
+    }
+}
+
+struct Qam16Args {
+    double *llr;  // [B][N], N % 4 == 0
+    long long B, first_frame;
+    int N;
+    double sigma, T;
+    uint64_t seed;
+};
+
+// all-zero codeword -> every symbol is gray[0] on both rails = level 2*0-3 = -3 (QAM_modulator.cpp:127-139);
+// received = symbol + sigmaQAM*g (fresh per frame); LLR = -Demodulate(...) (bp_simulation.cpp:626-628).
+__global__ void __launch_bounds__(256) awgn_qam16_llr_kernel(const Qam16Args a) {
+    const int ns = a.N >> 2;
+    const long long total = a.B * (long long)ns;
+    const double N0 = 2.0 * a.sigma * a.sigma;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / ns;
+        const int s = (int)(i - b * ns);
+        double g0, g1;
+        gauss_pair(a.seed, (uint64_t)(a.first_frame + b), (uint32_t)s, 1u, g0, g1);
+        const double xi = -3.0 + a.sigma * g0, xq = -3.0 + a.sigma * g1;
+        double b0, b1, b2, b3;
+        demod_rail16(xi, N0, a.T, 0, b0, b1);
+        demod_rail16(xq, N0, a.T, 0, b2, b3);
+        double *o = a.llr + b * (long long)a.N + 4 * s;
+        *reinterpret_cast<double2 *>(o) = make_double2(-b0, -b1);
+        *reinterpret_cast<double2 *>(o + 2) = make_double2(-b2, -b3);
+    }
+}
+
+// ---- error accounting -----------------------------------------------------------------------------------
+struct CountArgs {
+    const uint32_t *hard;  // [B][hard_words]
+    const int32_t *iters;  // [B]
+    int32_t *frame_info;   // [B] or null
+    unsigned long long *counters;  // [5]: nse, nde, nue, frames, sum |iters|
+    long long B;
+    int hard_words, R;
+};
+
+// One wavefront per frame: lanes read the frame's packed words coalesced, popcount, butterfly-reduce.
+// Block totals go out as one atomic per counter per block (Guideline 12).
+__global__ void __launch_bounds__(256) count_errors_kernel(const CountArgs a) {
+    __shared__ unsigned long long part[4][5];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long nse = 0, nde = 0, nue = 0, frames = 0, sit = 0;
+    for (long long fr = (long long)blockIdx.x * 4 + wv; fr < a.B; fr += (long long)gridDim.x * 4) {
+        uint32_t all = 0, info = 0;
+        for (int w = lane; w < a.hard_words; w += 64) {
+            const uint32_t x = a.hard[fr * a.hard_words + w];
+            all += __popc(x);
+            // information bits are indices >= R (bp_simulation.cpp:738)
+            const int lo = 32 * w;
+            uint32_t m = 0xffffffffu;
+            if (lo + 32 <= a.R) m = 0u;
+            else if (lo < a.R) m = 0xffffffffu << (a.R - lo);
+            info += __popc(x & m);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            all += __shfl_xor(all, o);
+            info += __shfl_xor(info, o);
+        }
+        if (lane == 0) {
+            const int it = a.iters[fr];
+            if (a.frame_info) a.frame_info[fr] = (int32_t)info | (all ? (1 << 30) : 0);
+            frames += 1;
+            sit += (unsigned long long)(it < 0 ? -it : it);
+            if (all) {                       // :805-810
+                nse += info;
+                nde += 1;
+                if (it >= 0) nue += 1;
+            }
+        }
+    }
+    if (lane == 0) { part[wv][0] = nse; part[wv][1] = nde; part[wv][2] = nue; part[wv][3] = frames; part[wv][4] = sit; }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const unsigned long long t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (t) atomicAdd(&a.counters[threadIdx.x], t);
+    }
+}
+
+}  // namespace ldpc

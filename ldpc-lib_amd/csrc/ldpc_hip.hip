@@ -1,0 +1,466 @@
+// ldpc_hip.hip -- C-ABI (include/ldpc_hip.h) over the gfx950 kernels.  Host side: context, code tables,
+// launch geometry, workspaces, HIP-event timing.  No CPU decode path exists in this library: every entry
+// point either runs the HIP kernels or fails with a message.
+#include "../../include/ldpc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ldpc_frontend.hpp"
+#include "ldpc_kernels.hpp"
+#include "ldpc_sumprod.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(LDPC_HIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kRHM = 16;   // block rows held in VGPRs by the min-sum kernels
+constexpr int kNHM = 32;   // block columns whose channel LLRs the flooding kernel keeps in VGPRs
+constexpr int kRWM = 16;   // max circulants per block row (edge-sign bits per row word)
+
+}  // namespace
+
+struct ldpc_hip_ctx {
+    int decoder_id = 0, device = 0;
+    int rh = 0, nh = 0, M = 0, N = 0, R = 0, ne = 0, hard_words = 0;
+    int max_rw = 0, max_cw = 0;
+    int F = 1;        // frames per workgroup (M <= 64: floor(64/M))
+    int threads = 64; // workgroup size of the decode kernel
+    bool multiwave = false;
+    size_t lds_bytes = 0;
+    // device tables
+    int32_t *d_row_start = nullptr, *d_col_start = nullptr;
+    uint32_t *d_edges = nullptr, *d_col_edges = nullptr, *d_col_slot = nullptr;
+    // workspace for ldpc_hip_simulate / decode_host
+    double *w_llr = nullptr;
+    uint32_t *w_hard = nullptr;
+    int32_t *w_iters = nullptr;
+    double *w_soft = nullptr;
+    unsigned long long *w_counters = nullptr;
+    long long w_frames = 0;
+    bool w_has_soft = false;
+    // HIP-event timing of decode launches
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double prof_ms = 0;
+    long long prof_launches = 0;
+};
+
+namespace {
+
+int set_device(const ldpc_hip_ctx *c) {
+    HIP_TRY(hipSetDevice(c->device));
+    return 0;
+}
+
+void free_workspace(ldpc_hip_ctx *c) {
+    if (c->w_llr) (void)hipFree(c->w_llr);
+    if (c->w_hard) (void)hipFree(c->w_hard);
+    if (c->w_iters) (void)hipFree(c->w_iters);
+    if (c->w_soft) (void)hipFree(c->w_soft);
+    c->w_llr = nullptr; c->w_hard = nullptr; c->w_iters = nullptr; c->w_soft = nullptr;
+    c->w_frames = 0; c->w_has_soft = false;
+}
+
+int ensure_workspace(ldpc_hip_ctx *c, long long B, bool need_soft) {
+    if (B <= c->w_frames && (!need_soft || c->w_has_soft)) return 0;
+    const long long nb = B > c->w_frames ? B : c->w_frames;
+    free_workspace(c);
+    HIP_TRY(hipMalloc(&c->w_llr, sizeof(double) * (size_t)nb * c->N));
+    HIP_TRY(hipMalloc(&c->w_hard, sizeof(uint32_t) * (size_t)nb * c->hard_words));
+    HIP_TRY(hipMalloc(&c->w_iters, sizeof(int32_t) * (size_t)nb));
+    if (need_soft) HIP_TRY(hipMalloc(&c->w_soft, sizeof(double) * (size_t)nb * c->N));
+    c->w_has_soft = need_soft;
+    c->w_frames = nb;
+    return 0;
+}
+
+template <typename K>
+int set_lds_limit(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bytes));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ldpc_hip_abi_version(void) { return LDPC_HIP_ABI_VERSION; }
+
+const char *ldpc_hip_last_error(void) { return g_err.c_str(); }
+
+int ldpc_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int device, ldpc_hip_ctx **out) {
+    if (out) *out = nullptr;
+    if (!out || !hd || rh <= 0 || nh <= 0 || M <= 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_open: bad argument");
+    if (decoder_id != LDPC_HIP_MS_DEC && decoder_id != LDPC_HIP_LMS_DEC && decoder_id != LDPC_HIP_SP_DEC)
+        return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_open: decoder id %d is not built (built: SP=1, MS=3, LMS=8)", decoder_id);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(LDPC_HIP_EINVAL, "ldpc_hip_open: device %d of %d", device, ndev);
+
+    ldpc_hip_ctx *c = new ldpc_hip_ctx();
+    c->decoder_id = decoder_id; c->device = device;
+    c->rh = rh; c->nh = nh; c->M = M; c->N = nh * M; c->R = rh * M;
+    c->hard_words = (c->N + 31) / 32;
+
+    std::vector<int32_t> row_start(rh + 1), col_start(nh + 1);
+    std::vector<uint32_t> edges, col_edges, col_slot;
+    std::vector<int> slot_of;  // per row-major edge: index inside its row
+    for (int j = 0; j < rh; ++j) {
+        row_start[j] = (int32_t)edges.size();
+        for (int k = 0; k < nh; ++k) {
+            int v = hd[j * nh + k];
+            if (v == -1) continue;
+            while (v < 0) v += M;   // rotate() reduces the shift like this (decoders.cpp:335-339)
+            while (v >= M) v -= M;
+            slot_of.push_back((int)edges.size() - row_start[j]);
+            edges.push_back(((uint32_t)k << 16) | (uint32_t)v);
+        }
+        const int rw = (int)edges.size() - row_start[j];
+        if (rw > c->max_rw) c->max_rw = rw;
+    }
+    row_start[rh] = (int32_t)edges.size();
+    c->ne = (int)edges.size();
+    for (int k = 0; k < nh; ++k) {
+        col_start[k] = (int32_t)col_edges.size();
+        for (int j = 0; j < rh; ++j)
+            for (int e = row_start[j]; e < row_start[j + 1]; ++e)
+                if ((int)(edges[e] >> 16) == k) {
+                    col_edges.push_back(((uint32_t)j << 16) | (edges[e] & 0xffffu));
+                    col_slot.push_back((uint32_t)e);  // global edge id (row-major)
+                }
+        const int cw = (int)col_edges.size() - col_start[k];
+        if (cw > c->max_cw) c->max_cw = cw;
+    }
+    col_start[nh] = (int32_t)col_edges.size();
+
+    // what the kernels were instantiated for
+    if (M >= 65536 || nh >= 65536) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "M and nh must be < 65536"); }
+    if (decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC) {
+        if (rh > kRHM) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "rh=%d > %d block rows", rh, kRHM); }
+        if (c->max_rw > kRWM) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "row weight %d > %d", c->max_rw, kRWM); }
+        if (decoder_id == LDPC_HIP_MS_DEC && nh > kNHM) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "nh=%d > %d block columns", nh, kNHM); }
+        if (M > 512) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "M=%d > 512", M); }
+        c->multiwave = M > 64;
+        c->F = c->multiwave ? 1 : 64 / M;
+        c->threads = c->multiwave ? ((M + 63) / 64) * 64 : 64;
+        c->lds_bytes = sizeof(double) * (size_t)c->N * c->F + 16;
+    } else {
+        c->multiwave = true;
+        c->F = 1;
+        c->threads = 256;
+        c->lds_bytes = ldpc::sp_lds_bytes(c->ne, M, c->R, c->N);
+        if (c->N > ldpc::kSpNVM * c->threads) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "sum-product: N=%d > %d", c->N, ldpc::kSpNVM * c->threads); }
+    }
+    if (c->lds_bytes > 160 * 1024) {
+        const size_t need = c->lds_bytes;
+        delete c;
+        return fail(LDPC_HIP_EUNSUPPORTED, "code needs %zu B of LDS per workgroup (> 160 KiB)", need);
+    }
+
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(&c->d_row_start, sizeof(int32_t) * (rh + 1));
+    if (e == hipSuccess) e = hipMalloc(&c->d_col_start, sizeof(int32_t) * (nh + 1));
+    if (e == hipSuccess) e = hipMalloc(&c->d_edges, sizeof(uint32_t) * (c->ne + 1));
+    if (e == hipSuccess) e = hipMalloc(&c->d_col_edges, sizeof(uint32_t) * (c->ne + 1));
+    if (e == hipSuccess) e = hipMalloc(&c->d_col_slot, sizeof(uint32_t) * (c->ne + 1));
+    if (e == hipSuccess) e = hipMalloc(&c->w_counters, sizeof(unsigned long long) * 8);
+    if (e == hipSuccess) e = hipMemcpy(c->d_row_start, row_start.data(), sizeof(int32_t) * (rh + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_col_start, col_start.data(), sizeof(int32_t) * (nh + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess && c->ne) e = hipMemcpy(c->d_edges, edges.data(), sizeof(uint32_t) * c->ne, hipMemcpyHostToDevice);
+    if (e == hipSuccess && c->ne) e = hipMemcpy(c->d_col_edges, col_edges.data(), sizeof(uint32_t) * c->ne, hipMemcpyHostToDevice);
+    if (e == hipSuccess && c->ne) e = hipMemcpy(c->d_col_slot, col_slot.data(), sizeof(uint32_t) * c->ne, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        ldpc_hip_close(c);
+        return fail(LDPC_HIP_EHIP, "ldpc_hip_open: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return 0;
+}
+
+void ldpc_hip_close(ldpc_hip_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    free_workspace(c);
+    if (c->d_row_start) (void)hipFree(c->d_row_start);
+    if (c->d_col_start) (void)hipFree(c->d_col_start);
+    if (c->d_edges) (void)hipFree(c->d_edges);
+    if (c->d_col_edges) (void)hipFree(c->d_col_edges);
+    if (c->d_col_slot) (void)hipFree(c->d_col_slot);
+    if (c->w_counters) (void)hipFree(c->w_counters);
+    for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    delete c;
+}
+
+int ldpc_hip_n(const ldpc_hip_ctx *c) { return c ? c->N : 0; }
+int ldpc_hip_r(const ldpc_hip_ctx *c) { return c ? c->R : 0; }
+int ldpc_hip_edges(const ldpc_hip_ctx *c) { return c ? c->ne : 0; }
+int ldpc_hip_hard_words(const ldpc_hip_ctx *c) { return c ? c->hard_words : 0; }
+
+int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int maxiter, double alpha,
+                        uint32_t *d_hard, int32_t *d_iters, double *d_soft, void *stream_) {
+    if (!c || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_decode_dev: bad argument");
+    if (B == 0) return 0;  // empty batch: nothing to do (an empty device tensor has a null pointer)
+    if (!d_llr) return fail(LDPC_HIP_EINVAL, "ldpc_hip_decode_dev: null llr");
+    if (int rc = set_device(c)) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+
+    ldpc::DecArgs a{};
+    a.llr = d_llr; a.hard = d_hard; a.iters = d_iters; a.soft_out = d_soft;
+    a.row_start = c->d_row_start; a.edges = c->d_edges;
+    a.col_start = c->d_col_start; a.col_edges = c->d_col_edges; a.col_slot = c->d_col_slot;
+    a.B = B; a.rh = c->rh; a.nh = c->nh; a.M = c->M; a.N = c->N; a.F = c->F;
+    a.maxiter = maxiter; a.hard_words = c->hard_words; a.alpha = alpha;
+
+    const long long blocks = (B + c->F - 1) / c->F;
+    if (blocks > 0x7fffffffLL) return fail(LDPC_HIP_EINVAL, "batch too large");
+    const dim3 grid((unsigned)blocks), block((unsigned)c->threads);
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (c->prof) {
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventRecord(ev0, stream));
+    }
+    switch (c->decoder_id) {
+    case LDPC_HIP_MS_DEC:
+        if (c->multiwave) {
+            auto k = ldpc::ms_flood_kernel<kRHM, kNHM, true>;
+            if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
+            hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
+        } else {
+            auto k = ldpc::ms_flood_kernel<kRHM, kNHM, false>;
+            if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
+            hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
+        }
+        break;
+    case LDPC_HIP_LMS_DEC:
+        if (c->multiwave) {
+            auto k = ldpc::lms_layered_kernel<kRHM, kRWM, true>;
+            if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
+            hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
+        } else {
+            auto k = ldpc::lms_layered_kernel<kRHM, kRWM, false>;
+            if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
+            hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
+        }
+        break;
+    case LDPC_HIP_SP_DEC: {
+        auto k = ldpc::sp_flood_kernel;
+        if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
+        hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
+        break;
+    }
+    default:
+        return fail(LDPC_HIP_EUNSUPPORTED, "decoder %d", c->decoder_id);
+    }
+    HIP_TRY(hipGetLastError());
+    if (c->prof) {
+        HIP_TRY(hipEventRecord(ev1, stream));
+        c->events.emplace_back(ev0, ev1);
+    }
+    return 0;
+}
+
+int ldpc_hip_decode_host(ldpc_hip_ctx *c, double *llr, long long B, int maxiter, int decision, double alpha,
+                         double *decword, int32_t *iters, int clobber_sp_input) {
+    if (!c || !llr || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_decode_host: bad argument");
+    if (B == 0) return 0;
+    if (int rc = set_device(c)) return rc;
+    const bool sp = c->decoder_id == LDPC_HIP_SP_DEC;
+    const bool need_soft = decision != 0 || (sp && clobber_sp_input);
+    if (int rc = ensure_workspace(c, B, need_soft)) return rc;
+    const size_t nllr = (size_t)B * c->N;
+    HIP_TRY(hipMemcpy(c->w_llr, llr, sizeof(double) * nllr, hipMemcpyHostToDevice));
+    if (int rc = ldpc_hip_decode_dev(c, c->w_llr, B, maxiter, alpha, c->w_hard, c->w_iters,
+                                     need_soft ? c->w_soft : nullptr, nullptr))
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (iters) HIP_TRY(hipMemcpy(iters, c->w_iters, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost));
+    std::vector<double> soft;
+    if (need_soft) {
+        soft.resize(nllr);
+        HIP_TRY(hipMemcpy(soft.data(), c->w_soft, sizeof(double) * nllr, hipMemcpyDeviceToHost));
+    }
+    if (decword) {
+        if (decision) {
+            std::memcpy(decword, soft.data(), sizeof(double) * nllr);
+        } else {
+            std::vector<uint32_t> hard((size_t)B * c->hard_words);
+            HIP_TRY(hipMemcpy(hard.data(), c->w_hard, sizeof(uint32_t) * hard.size(), hipMemcpyDeviceToHost));
+            for (long long b = 0; b < B; ++b)
+                for (int v = 0; v < c->N; ++v)
+                    decword[(size_t)b * c->N + v] = (double)((hard[(size_t)b * c->hard_words + (v >> 5)] >> (v & 31)) & 1u);
+        }
+    }
+    if (sp && clobber_sp_input) std::memcpy(llr, soft.data(), sizeof(double) * nllr);  // decoders.cpp:1950,2124
+    return 0;
+}
+
+static int awgn_sigma(const ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, double *sigma) {
+    const int b = c->rh, cc = c->nh;
+    if (punctured_blocks < 0 || punctured_blocks >= cc) return fail(LDPC_HIP_EINVAL, "punctured_blocks=%d", punctured_blocks);
+    const double bitrate = (double)(cc - b) / (cc - punctured_blocks);  // bp_simulation.cpp:444
+    if (modulation_type == 0) {
+        *sigma = std::sqrt(std::pow(10, -snr_db / 10) / 2 / bitrate);    // :445
+    } else if (modulation_type == 1 || modulation_type == 2) {
+        const int QAM = modulation_type == 1 ? 4 : 16, halfmlog = modulation_type == 1 ? 1 : 2;
+        const double norm_factor = 2.0 * (QAM - 1.0) / 3.0;              // :447
+        *sigma = std::sqrt(std::pow(10., -snr_db / 10.) / (2 * bitrate * halfmlog * 2) * norm_factor);  // :449
+    } else {
+        return fail(LDPC_HIP_EUNSUPPORTED, "modulation_type %d", modulation_type);
+    }
+    return 0;
+}
+
+int ldpc_hip_awgn_llr_dev(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, uint64_t seed,
+                          long long first_frame, long long B, double *d_llr, void *stream_) {
+    if (!c || !d_llr || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_awgn_llr_dev: bad argument");
+    if (modulation_type != 0 && modulation_type != 1) return fail(LDPC_HIP_EUNSUPPORTED, "modulation_type %d (0 BPSK, 1 QAM4)", modulation_type);
+    if (B == 0) return 0;
+    if (int rc = set_device(c)) return rc;
+    ldpc::AwgnArgs a{};
+    if (int rc = awgn_sigma(c, snr_db, modulation_type, punctured_blocks, &a.sigma)) return rc;
+    a.llr = d_llr; a.B = B; a.first_frame = first_frame; a.N = c->N;
+    a.punct_start = c->N - c->M * punctured_blocks;
+    a.punct_val = c->decoder_id == LDPC_HIP_SP_DEC ? 0.0 : 0.5;  // :700 (sic)
+    a.seed = seed;
+    const long long total = B * (long long)((c->N + 1) / 2);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(ldpc::awgn_llr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ldpc_hip_awgn_qam16_llr_dev(ldpc_hip_ctx *c, double snr_db, double T, uint64_t seed, long long first_frame,
+                                long long B, double *d_llr, void *stream_) {
+    if (!c || !d_llr || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_awgn_qam16_llr_dev: bad argument");
+    if (c->N % 4) return fail(LDPC_HIP_EUNSUPPORTED, "16-QAM needs N %% 4 == 0 (N=%d)", c->N);
+    if (B == 0) return 0;
+    if (int rc = set_device(c)) return rc;
+    ldpc::Qam16Args a{};
+    if (int rc = awgn_sigma(c, snr_db, 2, 0, &a.sigma)) return rc;
+    a.llr = d_llr; a.B = B; a.first_frame = first_frame; a.N = c->N; a.T = T; a.seed = seed;
+    const long long total = B * (long long)(c->N / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(ldpc::awgn_qam16_llr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ldpc_hip_qam_demod_dev(int Q, double T, double sigma, const double *d_x, long long ns, double *d_out,
+                           int out_type, int device, void *stream_) {
+    if (!d_x || !d_out || ns < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_qam_demod_dev: bad argument");
+    if (Q != 4 && Q != 16) return fail(LDPC_HIP_EUNSUPPORTED, "QAM-%d demapper not built (4, 16)", Q);
+    if (Q == 4 && out_type != 0) return fail(LDPC_HIP_EUNSUPPORTED, "QAM-4 probability output not built");
+    if (ns == 0) return 0;
+    HIP_TRY(hipSetDevice(device));
+    ldpc::DemodArgs a{};
+    a.x = d_x; a.out = d_out; a.ns = ns; a.Q = Q; a.out_type = out_type; a.T = T; a.sigma = sigma;
+    long long blocks = (ns + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(ldpc::qam_demod_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ldpc_hip_count_errors_dev(ldpc_hip_ctx *c, const uint32_t *d_hard, const int32_t *d_iters, long long B,
+                              int32_t *d_frame_info, unsigned long long *d_counters, void *stream_) {
+    if (!c || !d_hard || !d_iters || !d_counters || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_count_errors_dev: bad argument");
+    if (B == 0) return 0;
+    if (int rc = set_device(c)) return rc;
+    ldpc::CountArgs a{};
+    a.hard = d_hard; a.iters = d_iters; a.frame_info = d_frame_info; a.counters = d_counters;
+    a.B = B; a.hard_words = c->hard_words; a.R = c->R;
+    long long blocks = (B + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(ldpc::count_errors_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ldpc_hip_simulate(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, int maxiter,
+                      double alpha, uint64_t seed, long long first_frame, long long B, unsigned long long counters[4],
+                      unsigned long long *sum_abs_iters) {
+    if (!c || !counters || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_simulate: bad argument");
+    if (int rc = set_device(c)) return rc;
+    const long long chunk_max = 1 << 16;
+    const long long chunk = B < chunk_max ? B : chunk_max;
+    if (chunk > 0) { if (int rc = ensure_workspace(c, chunk, false)) return rc; }
+    HIP_TRY(hipMemsetAsync(c->w_counters, 0, sizeof(unsigned long long) * 8, nullptr));
+    for (long long done = 0; done < B; done += chunk) {
+        const long long nb = (B - done) < chunk ? (B - done) : chunk;
+        int rc;
+        if (modulation_type == 2) rc = ldpc_hip_awgn_qam16_llr_dev(c, snr_db, 26.0, seed, first_frame + done, nb, c->w_llr, nullptr);
+        else rc = ldpc_hip_awgn_llr_dev(c, snr_db, modulation_type, punctured_blocks, seed, first_frame + done, nb, c->w_llr, nullptr);
+        if (rc) return rc;
+        if ((rc = ldpc_hip_decode_dev(c, c->w_llr, nb, maxiter, alpha, c->w_hard, c->w_iters, nullptr, nullptr))) return rc;
+        if ((rc = ldpc_hip_count_errors_dev(c, c->w_hard, c->w_iters, nb, nullptr, c->w_counters, nullptr))) return rc;
+    }
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpy(h, c->w_counters, sizeof h, hipMemcpyDeviceToHost));
+    counters[0] = h[0]; counters[1] = h[1]; counters[2] = h[2]; counters[3] = h[3];
+    if (sum_abs_iters) *sum_abs_iters = h[4];
+    return 0;
+}
+
+int ldpc_hip_profile_enable(ldpc_hip_ctx *c, int enable) {
+    if (!c) return fail(LDPC_HIP_EINVAL, "null ctx");
+    c->prof = enable != 0;
+    return 0;
+}
+
+int ldpc_hip_profile_read(ldpc_hip_ctx *c, double *total_ms, long long *launches, int reset) {
+    if (!c) return fail(LDPC_HIP_EINVAL, "null ctx");
+    if (int rc = set_device(c)) return rc;
+    for (auto &ev : c->events) {
+        HIP_TRY(hipEventSynchronize(ev.second));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        c->prof_ms += ms;
+        c->prof_launches += 1;
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    c->events.clear();
+    if (total_ms) *total_ms = c->prof_ms;
+    if (launches) *launches = c->prof_launches;
+    if (reset) { c->prof_ms = 0; c->prof_launches = 0; }
+    return 0;
+}
+
+}  // extern "C"

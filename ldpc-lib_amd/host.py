@@ -1,0 +1,91 @@
+"""Host-side mirror of the upstream Monte-Carlo harness for the Python callers (bench.py, tests).
+
+`bp_simulation()` keeps upstream's argument meaning, counters, stopping rule and return value
+(bp_simulation.h:9-27, bp_simulation.cpp:305-841) but draws the channel noise on the GPU (counter-based Philox keyed by
+the global frame index), decodes frames in batches and -- because the upstream stopping rule is sequential in frame
+order (bp_simulation.cpp:591,820) -- replays that rule over the ordered per-frame records of each batch, so the result
+is exactly what a frame-by-frame loop over the same noise would return, whatever the batch size or GPU count.
+
+The bit-exact drop-in for upstream's C++ callers (same mt19937 noise as upstream) is the C++ layer in
+csrc/compat/; this module is its throughput-mode sibling.
+"""
+import numpy as np
+
+from .binding import DEC_IMS, DEC_LMS, DEC_MS, DEC_SP, LdpcHip, LdpcHipError
+
+MODULATION_SKIP, MODULATION_QAM4, MODULATION_QAM16 = 0, 1, 2  # modulation.h:4-11
+
+
+def relift_base_matrix(H, M):
+    """main_simulation.cpp:400-414: entries > 0 become entry % M; in column rows-1 a result of 0 becomes 1."""
+    H = np.array(H, dtype=np.int32, copy=True)
+    rows = H.shape[0]
+    pos = H > 0
+    H[pos] = H[pos] % M
+    col = H[:, rows - 1]
+    col[pos[:, rows - 1] & (col == 0)] = 1
+    return H
+
+
+def replay_stopping_rule(frame_info, iters, state, n_frame_errors, n_experiments, reference_frame_error):
+    """Apply the frame loop of bp_simulation.cpp:591-823 to one ordered batch of per-frame records.
+
+    frame_info[i]: wrong information bits of frame i, bit 30 set when the frame has any wrong bit.
+    state: dict(nse, nde, nue, experiment), updated in place.  Returns True when the simulation stops inside or
+    right after this batch.  Error-free frames only advance `experiment`, so the walk visits errored frames only."""
+    if not (state["nde"] < n_frame_errors and state["experiment"] <= n_experiments):
+        return True
+    B = len(frame_info)
+    bad = np.flatnonzero((frame_info & (1 << 30)) != 0)
+    idx = 0
+    for b in bad:
+        clean = int(b) - idx
+        room = n_experiments + 1 - state["experiment"]  # frames `experiment <= n_experiments` still admits (:591)
+        if clean >= room:
+            state["experiment"] += room
+            return True
+        state["experiment"] += clean + 1
+        state["nse"] += int(frame_info[b]) & ((1 << 30) - 1)  # :807
+        state["nde"] += 1                                      # :808
+        if iters[b] >= 0:
+            state["nue"] += 1                                  # :809-810
+        if state["nde"] >= 10 and state["nde"] / state["experiment"] > 2.5 * reference_frame_error:
+            return True                                        # :820
+        if state["nde"] >= n_frame_errors:
+            return True                                        # :591 fails before the next frame
+        idx = int(b) + 1
+    clean = B - idx
+    room = n_experiments + 1 - state["experiment"]
+    if clean >= room:
+        state["experiment"] += room
+        return True
+    state["experiment"] += clean
+    return False
+
+
+def bp_simulation(H, tailbite_length, max_iterations, n_frame_errors, n_experiments, snr, reference_frame_error,
+                  decoder_type=DEC_MS, modulation_type=MODULATION_SKIP, punctured_blocks=0, seed=1, device=0,
+                  batch=16384, first_frame=0, frame_stride=1, alpha=0.8, return_state=False):
+    """Returns (BER, FER) = (nse/experiment/(n-r), nde/experiment) like bp_simulation.cpp:840."""
+    import torch
+    H = np.asarray(H)
+    with LdpcHip(decoder_type, H, tailbite_length, device) as dec:
+        n, r = dec.N, dec.R
+        state = {"nse": 0, "nde": 0, "nue": 0, "experiment": 0, "sum_abs_iters": 0}
+        base = first_frame
+        stop = False
+        while not stop:
+            B = int(min(batch, max(1, n_experiments + 1 - state["experiment"])))
+            llr = dec.awgn_llr(snr, seed, base, B, modulation=modulation_type, punctured_blocks=punctured_blocks)
+            hard, iters, _ = dec.decode(llr, max_iterations, alpha=alpha)
+            _, info = dec.count_errors(hard, iters, want_frame_info=True)
+            torch.cuda.synchronize(device)
+            info_h, iters_h = info.cpu().numpy(), iters.cpu().numpy()
+            before = state["experiment"]
+            stop = replay_stopping_rule(info_h, iters_h, state, n_frame_errors, n_experiments, reference_frame_error)
+            used = state["experiment"] - before
+            state["sum_abs_iters"] += int(np.abs(iters_h[:used]).sum())
+            base += B
+    ber = state["nse"] / state["experiment"] / (n - r)
+    fer = state["nde"] / state["experiment"]
+    return (ber, fer, state) if return_state else (ber, fer)

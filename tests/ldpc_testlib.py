@@ -206,3 +206,69 @@ def pack_bits(dec):
     bits = np.zeros((B, W * 32), dtype=np.uint8)
     bits[:, :N] = dec != 0
     return np.packbits(bits.reshape(B, W, 32), axis=2, bitorder="little").view(np.uint32).reshape(B, W)
+
+
+# ---- CPU twin of the device noise generator (ldpc-lib_amd/csrc/ldpc_frontend.hpp) ---------------------------------
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10 (Salmon et al. 2011).  All arguments uint32 arrays (broadcastable)."""
+    c = [np.asarray(x, dtype=np.uint64) for x in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0 = np.uint64(k0)
+    k1 = np.uint64(k1)
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = M0 * c[0]
+        p1 = M1 * c[2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[1] ^ k0) & mask
+        n1 = p1 & mask
+        n2 = ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & mask
+        n3 = p0 & mask
+        c = [n0, n1, n2, n3]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return [x.astype(np.uint32) for x in c]
+
+
+def philox_gauss_pairs(seed, frames, npairs, tag=0):
+    """Box-Muller pairs exactly as gauss_pair() on the device (up to libm-vs-ocml rounding): returns [len(frames), 2*npairs]."""
+    frames = np.asarray(frames, dtype=np.uint64)[:, None]
+    pair = np.arange(npairs, dtype=np.uint64)[None, :]
+    x = philox4x32_10(frames & np.uint64(0xFFFFFFFF), frames >> np.uint64(32), pair, np.uint64(tag),
+                      np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32))
+    a = ((x[0].astype(np.uint64) << np.uint64(32)) | x[1].astype(np.uint64)) >> np.uint64(11)
+    b = ((x[2].astype(np.uint64) << np.uint64(32)) | x[3].astype(np.uint64)) >> np.uint64(11)
+    u1 = (a.astype(np.float64) + 0.5) / 9007199254740992.0
+    u2 = (b.astype(np.float64) + 0.5) / 9007199254740992.0
+    rad = np.sqrt(-2.0 * np.log(u1))
+    g = np.empty((frames.shape[0], 2 * npairs))
+    g[:, 0::2] = rad * np.cos(2.0 * np.pi * u2)
+    g[:, 1::2] = rad * np.sin(2.0 * np.pi * u2)
+    return g
+
+
+def bpsk_sigma(H, snr_db, punctured_blocks=0):
+    rh, nh = H.shape
+    rate = (nh - rh) / (nh - punctured_blocks)
+    return np.sqrt(10.0 ** (-snr_db / 10.0) / 2 / rate)   # bp_simulation.cpp:444-445
+
+
+def syndrome_np(H, M, hard_bits):
+    """hard_bits [B,N] 0/1 -> [B] bool: any parity check fails (edge rule: check (j,n) -- variable (k,(n+c)%M))."""
+    hard_bits = np.asarray(hard_bits, dtype=np.uint8)
+    B = hard_bits.shape[0]
+    rh, nh = H.shape
+    cols = hard_bits.reshape(B, nh, M)
+    fail = np.zeros(B, dtype=bool)
+    for j in range(rh):
+        s = np.zeros((B, M), dtype=np.uint8)
+        for k in range(nh):
+            if H[j, k] >= 0:
+                s ^= np.roll(cols[:, k, :], -int(H[j, k]) % M, axis=1)
+        fail |= s.any(axis=1)
+    return fail
+
+
+def unpack_bits(hard_words, N):
+    """packed uint32 [B,W] -> [B,N] uint8"""
+    w = np.ascontiguousarray(hard_words).view(np.uint32)
+    bits = np.unpackbits(w.view(np.uint8).reshape(w.shape[0], -1), axis=1, bitorder="little")
+    return bits[:, :N]

@@ -1,0 +1,258 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C-ABI library (libldpc_hip.so);
+the oracle (oracle/) is only the checker."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from ldpc_testlib import (GOLDEN_DIR, LMS_DEC, MS_DEC, SP_DEC, Oracle, awgn_llr, bpsk_sigma, load_base_matrix, pack_bits,
+                          philox_gauss_pairs, relift, syndrome_np, unpack_bits)
+
+pytestmark = pytest.mark.gpu
+
+DECODER_SETS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                      if os.path.basename(p).split("_")[0] in ("ms", "lms", "sp"))
+
+# sum-product soft values: exp() is ocml on the device and glibc in the reference (each within 1 ulp of the true
+# value, not identical to each other); every other operation is IEEE-exact and in the reference's order.  The 1-ulp
+# input difference is amplified by up to 50 iterations of products and (1+A)/(1-A) maps; measured worst case on these
+# sets is 1e-8 relative.  STATED TOLERANCE for sum-product a-posteriori likelihood ratios: relative 1e-6.
+# Hard decisions and iteration counts are required to be identical.  MS/LMS are exact (tolerance 0).
+SP_RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def L():
+    import ldpc_lib_amd
+    return ldpc_lib_amd
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+@pytest.mark.parametrize("name", DECODER_SETS)
+def test_golden_vectors_host_api(L, name):
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    H, M, dec_id, maxiter = g["H"], int(g["M"]), int(g["dec_id"]), int(g["maxiter"])
+    with L.LdpcHip(dec_id, H, M) as dec:
+        d0, it0, after = dec.decode_host(g["llr"], maxiter, decision=0)
+        assert np.array_equal(it0, g["iters"]), (it0, g["iters"])
+        assert np.array_equal(pack_bits(d0), g["hard"])
+        ns = g["soft"].shape[0]
+        d1, it1, _ = dec.decode_host(g["llr"][:ns], maxiter, decision=1)
+        assert np.array_equal(it1, g["iters"][:ns])
+        if dec_id == SP_DEC:
+            np.testing.assert_allclose(d1, g["soft"], rtol=SP_RTOL, atol=0)
+        else:
+            assert np.array_equal(d1, g["soft"])  # bit-exact a-posteriori LLRs
+            assert np.array_equal(after, g["llr"])  # MS/LMS leave their input intact
+
+
+@pytest.mark.parametrize("dec_id,M,snrs,frames,maxiter", [
+    (MS_DEC, 64, (0.5, 1.2, 1.6, 2.0, 3.0), 160, 50),
+    (MS_DEC, 64, (1.4,), 300, 7),
+    (LMS_DEC, 64, (0.8, 1.2, 1.6, 2.5), 160, 50),
+    (SP_DEC, 64, (1.0, 1.5, 2.0), 100, 50),
+    (MS_DEC, 16, (2.5,), 203, 50),      # F = 4 frames per wave, ragged last wave
+    (MS_DEC, 7, (3.0,), 100, 30),       # F = 9, 63 of 64 lanes used
+    (LMS_DEC, 24, (2.5,), 77, 50),      # F = 2, lanes 48..63 idle
+    (MS_DEC, 100, (1.8,), 24, 50),      # 2 waves per frame, 28 idle lanes
+    (LMS_DEC, 200, (1.5,), 12, 50),     # 4 waves per frame
+    (SP_DEC, 33, (2.0,), 40, 25),
+])
+def test_random_batches_against_oracle(L, torch, dec_id, M, snrs, frames, maxiter):
+    H = relift(load_base_matrix(), M)
+    llr = np.concatenate([awgn_llr(H, M, s, 100 + i, frames // len(snrs) + 1) for i, s in enumerate(snrs)])[:frames]
+    o = Oracle(H, M)
+    d_ref, it_ref, _ = o.decode(dec_id, llr, maxiter, 0)
+    with L.LdpcHip(dec_id, H, M) as dec:
+        x = torch.from_numpy(llr).cuda()
+        hard, iters, soft = dec.decode(x, maxiter, want_soft=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(iters.cpu().numpy(), it_ref)
+        assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
+        assert np.array_equal(x.cpu().numpy(), llr)  # the device entry point never modifies its input
+        s_ref, _, _ = o.decode(dec_id, llr, maxiter, 1)
+        if dec_id == SP_DEC:
+            np.testing.assert_allclose(soft.cpu().numpy(), s_ref, rtol=SP_RTOL)
+        else:
+            assert np.array_equal(soft.cpu().numpy(), s_ref)
+
+
+def test_edge_case_inputs(L, torch):
+    """zeros, negative zeros, huge magnitudes (MAX_VAL clamp, decoders.cpp:4730), B = 0 / 1, ragged waves."""
+    H = relift(load_base_matrix(), 64)
+    N = 32 * 64
+    rng = np.random.RandomState(5)
+    llr = awgn_llr(H, 64, 1.5, 9, 12)
+    llr[0] = 0.0
+    llr[1] = -0.0
+    llr[2] = np.where(rng.rand(N) < 0.5, -0.0, 0.0)
+    llr[3] *= 1e6                                   # every |v2c| clamps to 32767
+    llr[4, ::7] = 0.0
+    llr[5, ::5] = -0.0
+    llr[6] = np.abs(llr[6])                         # already a codeword
+    llr[7] = 1e-310 * np.sign(llr[7])               # denormals
+    o = Oracle(H, 64)
+    for dec_id in (MS_DEC, LMS_DEC):
+        d_ref, it_ref, _ = o.decode(dec_id, llr, 50, 0)
+        with L.LdpcHip(dec_id, H, 64) as dec:
+            d, it, _ = dec.decode_host(llr, 50)
+            assert np.array_equal(it, it_ref), (dec_id, it, it_ref)
+            assert np.array_equal(d, d_ref)
+            d1, it1, _ = dec.decode_host(llr[3], 50)   # B = 1, 1-D input
+            assert it1 == it_ref[3] and np.array_equal(d1, d_ref[3])
+            e = torch.empty((0, N), dtype=torch.float64, device="cuda")
+            hard, iters, _ = dec.decode(e, 50)
+            assert hard.shape[0] == 0 and iters.shape[0] == 0
+    # sum-product: already-a-codeword returns 0 (decoders.cpp:1989-2002), |LLR| > 20 clamps (INPUT_LIMIT)
+    llr_sp = awgn_llr(H, 64, 2.0, 3, 4)
+    llr_sp[0] = np.abs(llr_sp[0]) + 0.1
+    llr_sp[1] *= 40.0
+    d_ref, it_ref, after_ref = o.decode(SP_DEC, llr_sp, 50, 0)
+    with L.LdpcHip(SP_DEC, H, 64) as dec:
+        d, it, after = dec.decode_host(llr_sp, 50)
+        assert it_ref[0] == 0 and np.array_equal(it, it_ref)
+        assert np.array_equal(d, d_ref)
+        np.testing.assert_allclose(after, after_ref, rtol=SP_RTOL)  # upstream clobbers soft[] with the ratios
+
+
+def test_maxiter_one_and_unsupported_shapes(L):
+    H = relift(load_base_matrix(), 64)
+    llr = awgn_llr(H, 64, 1.0, 4, 8)
+    o = Oracle(H, 64)
+    for dec_id in (MS_DEC, LMS_DEC, SP_DEC):
+        d_ref, it_ref, _ = o.decode(dec_id, llr, 1, 0)
+        with L.LdpcHip(dec_id, H, 64) as dec:
+            d, it, _ = dec.decode_host(llr, 1)
+            assert np.array_equal(it, it_ref) and np.array_equal(d, d_ref)
+    with pytest.raises(L.LdpcHipError):
+        L.LdpcHip(6, H, 64)  # FHT_DEC (GF(q)) is out of scope: fails loudly, no fallback
+    with pytest.raises(L.LdpcHipError):
+        L.LdpcHip(MS_DEC, np.zeros((40, 80), dtype=np.int16), 64)  # more block rows than the kernel holds in VGPRs
+
+
+def test_full_size_properties(L, torch):
+    """BASELINE config #2 size (65536 frames of the (2048,1024) code): size-independent properties."""
+    H = relift(load_base_matrix(), 64)
+    B, N = 65536, 2048
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        llr = dec.awgn_llr(2.0, seed=7, first_frame=0, B=B)
+        hard, iters, _ = dec.decode(llr, 50)
+        torch.cuda.synchronize()
+        it = iters.cpu().numpy()
+        bits = unpack_bits(hard.cpu().numpy(), N)
+        conv = it > 0
+        assert 0.9 < conv.mean() < 1.0                       # FER ~4 % at 2.0 dB
+        # 1. every frame reported as converged satisfies all parity checks; none of the others does
+        fail = syndrome_np(H, 64, bits)
+        assert not fail[conv].any() and fail[~conv].all()
+        assert (it[~conv] == -50).all() and it[conv].max() <= 50 and it[conv].min() >= 1
+        # 2. batch-split invariance: any sub-batch decodes to the same words
+        h2, i2, _ = dec.decode(llr[1000:1777].contiguous(), 50)
+        assert torch.equal(h2, hard[1000:1777]) and torch.equal(i2, iters[1000:1777])
+        # 3. idempotence: a decoded codeword fed back as a confident LLR is returned unchanged in one iteration
+        sel = np.flatnonzero(conv)[:4096]
+        cw = torch.from_numpy(bits[sel].astype(np.float64)).cuda()
+        h3, i3, _ = dec.decode((1.0 - 2.0 * cw) * 8.0, 50)
+        assert (i3 == 1).all() and torch.equal(h3, hard[torch.from_numpy(sel).cuda()])
+        # 4. sample cross-check against the oracle at this size (first and last 24 frames)
+        o = Oracle(H, 64)
+        for sl in (slice(0, 24), slice(B - 24, B)):
+            d_ref, it_ref, _ = o.decode(MS_DEC, llr[sl].cpu().numpy(), 50, 0)
+            assert np.array_equal(it[sl], it_ref) and np.array_equal(bits[sl], d_ref.astype(np.uint8))
+        # 5. linearity of the channel symmetry: negating the LLRs of a codeword's support flips the decoded bits
+        c = bits[sel[0]].astype(np.float64)
+        y = llr[:64].clone()
+        y_flipped = y * torch.from_numpy(1.0 - 2.0 * c).cuda()
+        ha, ia, _ = dec.decode(y, 50)
+        hb, ib, _ = dec.decode(y_flipped, 50)
+        cw_words = torch.from_numpy(pack_bits(c[None, :]).view(np.int32)).cuda()
+        assert torch.equal(ia, ib) and torch.equal(ha ^ cw_words, hb)
+
+
+def test_device_noise_counting_and_simulate(L, torch):
+    H = relift(load_base_matrix(), 64)
+    N, R = 2048, 1024
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        B, first = 300, 123456789012
+        llr = dec.awgn_llr(1.4, seed=(5 << 32) | 77, first_frame=first, B=B)
+        # noise generator against its CPU twin (Philox stream is exact; Box-Muller differs by libm/ocml rounding)
+        sigma = bpsk_sigma(H, 1.4)
+        g = philox_gauss_pairs((5 << 32) | 77, first + np.arange(B), N // 2)
+        ref = -2.0 * (sigma * g + 2.0 * 0.0 - 1.0) / (sigma * sigma)
+        np.testing.assert_allclose(llr.cpu().numpy(), ref, rtol=1e-11, atol=1e-11)
+        # frames are keyed by their global index: a shifted window reproduces the overlap
+        llr2 = dec.awgn_llr(1.4, seed=(5 << 32) | 77, first_frame=first + 100, B=50)
+        assert torch.equal(llr2, llr[100:150])
+        # puncturing (bp_simulation.cpp:697-710): last M*blocks LLRs are 0.5 for LLR decoders
+        llr3 = dec.awgn_llr(1.4, seed=1, first_frame=0, B=4, punctured_blocks=2)
+        assert (llr3[:, N - 128:] == 0.5).all() and not (llr3[:, :N - 128] == 0.5).any()
+        # error accounting against numpy
+        hard, iters, _ = dec.decode(llr, 50)
+        cnt, info = dec.count_errors(hard, iters, want_frame_info=True)
+        torch.cuda.synchronize()
+        bits = unpack_bits(hard.cpu().numpy(), N)
+        it = iters.cpu().numpy()
+        bad = bits.any(axis=1)
+        exp = [int(bits[bad][:, R:].sum()), int(bad.sum()), int((bad & (it >= 0)).sum()), B, int(np.abs(it).sum())]
+        assert cnt.cpu().tolist() == exp
+        inf = info.cpu().numpy()
+        assert np.array_equal((inf & (1 << 30)) != 0, bad) and np.array_equal(inf & 0xFFFFF, bits[:, R:].sum(axis=1))
+        # fused simulate == composition, and independent of how the frame range is chunked
+        s = dec.simulate(1.4, 50, seed=(5 << 32) | 77, first_frame=first, B=B)
+        assert [s["nse"], s["nde"], s["nue"], s["frames"], s["sum_abs_iters"]] == exp
+        a = dec.simulate(1.4, 50, seed=(5 << 32) | 77, first_frame=first, B=100)
+        b = dec.simulate(1.4, 50, seed=(5 << 32) | 77, first_frame=first + 100, B=200)
+        assert all(a[k] + b[k] == s[k] for k in s)
+
+
+def test_host_bp_simulation_replays_the_sequential_rule(L, torch):
+    """ldpc_lib_amd.bp_simulation (batched, GPU) == frame-by-frame loop with the oracle decoder over the same noise."""
+    H = relift(load_base_matrix(), 64)
+    n_exp, n_fe, ref_fer, snr, seed = 700, 12, 0.02, 1.3, 99
+    ber, fer, st = L.bp_simulation(H, 64, 50, n_fe, n_exp, snr, ref_fer, decoder_type=MS_DEC, seed=seed, batch=256,
+                                   return_state=True)
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        llr = dec.awgn_llr(snr, seed, 0, st["experiment"] + 5).cpu().numpy()
+    o = Oracle(H, 64)
+    nse = nde = nue = exp = 0
+    while nde < n_fe and exp <= n_exp:          # bp_simulation.cpp:591-823
+        d, it, _ = o.decode(MS_DEC, llr[exp], 50, 0)
+        exp += 1
+        if d.any():
+            nse += int(d[1024:].sum()); nde += 1; nue += it >= 0
+            if nde >= 10 and nde / exp > 2.5 * ref_fer:
+                break
+    assert (st["nse"], st["nde"], st["nue"], st["experiment"]) == (nse, nde, nue, exp)
+    assert ber == nse / exp / 1024 and fer == nde / exp
+
+
+def test_qam_frontend(L, torch):
+    from ldpc_lib_amd.binding import qam_demod
+    g = np.load(os.path.join(GOLDEN_DIR, "qam_frontend.npz"))
+    for out_type in (0, 1):
+        for s in ("0p35", "0p8", "2p5"):
+            key = f"q16_t{out_type}_s{s}"
+            x = torch.from_numpy(g[key + "_x"].reshape(-1, 2)).cuda()
+            out = qam_demod(x, 16, 26.0, float(s.replace("p", ".")), out_type).cpu().numpy().ravel()
+            ref = g[key + "_llr"]
+            nan = np.isnan(ref)
+            assert np.array_equal(np.isnan(out), nan)
+            np.testing.assert_allclose(out[~nan], ref[~nan], rtol=1e-12, atol=1e-13)
+    key = "q4_t0_s0p8"
+    x = torch.from_numpy(g[key + "_x"].reshape(-1, 2)).cuda()
+    out = qam_demod(x, 4, 26.0, 0.8, 0).cpu().numpy().ravel()
+    assert np.array_equal(out, g[key + "_llr"])
+    # 16-QAM chain: statistics of the LLRs of the all-zero codeword + decodes at a reasonable Eb/N0
+    H = relift(load_base_matrix(), 64)
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        llr = dec.awgn_llr(6.0, seed=3, first_frame=0, B=512, modulation=2)
+        hard, iters, _ = dec.decode(llr, 50)
+        assert (llr > 0).double().mean().item() > 0.9
+        assert (iters > 0).double().mean().item() > 0.95
