@@ -8,12 +8,14 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "ldpc_frontend.hpp"
 #include "ldpc_kernels.hpp"
+#include "ldpc_ms_fast.hpp"
 #include "ldpc_sumprod.hpp"
 
 namespace {
@@ -51,6 +53,9 @@ struct ldpc_hip_ctx {
     int threads = 64; // workgroup size of the decode kernel
     bool multiwave = false;
     size_t lds_bytes = 0;
+    bool fast_m64 = false;     // flagship path: min-sum, M == 64, table in the kernel-argument segment
+    int fast_variant = 0;      // 0 = LDS fp64 atomics, 1 = read-add-write (A/B switch, LDPC_HIP_MS_VARIANT)
+    ldpc::FastTab fast_tab;
     // device tables
     int32_t *d_row_start = nullptr, *d_col_start = nullptr;
     uint32_t *d_edges = nullptr, *d_col_edges = nullptr, *d_col_slot = nullptr;
@@ -177,6 +182,25 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
         c->F = c->multiwave ? 1 : 64 / M;
         c->threads = c->multiwave ? ((M + 63) / 64) * 64 : 64;
         c->lds_bytes = sizeof(double) * (size_t)c->N * c->F + 16;
+        bool all_cols_used = true;
+        for (int k = 0; k < nh; ++k) all_cols_used = all_cols_used && (col_start[k + 1] > col_start[k]);
+        if (decoder_id == LDPC_HIP_MS_DEC && M == 64 && rh <= ldpc::kFastRows && nh <= ldpc::kFastCols &&
+            c->max_rw <= ldpc::kFastSlots && all_cols_used) {
+            c->fast_m64 = true;
+            const char *v = getenv("LDPC_HIP_MS_VARIANT");
+            c->fast_variant = v ? atoi(v) : 0;
+            std::memset(&c->fast_tab, 0, sizeof c->fast_tab);
+            std::vector<char> seen(nh, 0);
+            for (int j = 0; j < rh; ++j)
+                for (int e = row_start[j]; e < row_start[j + 1]; ++e) {
+                    const uint32_t k = edges[e] >> 16, sh = edges[e] & 0xffffu;
+                    const uint32_t first = seen[k] ? 0u : 1u;  // rows ascend: the first hit is the column's first edge
+                    seen[k] = 1;
+                    const int slot = e - row_start[j];
+                    c->fast_tab.pk[j][slot >> 1] |= ldpc::fast_desc(first, k, sh) << ((slot & 1) * 16);
+                }
+            c->lds_bytes = sizeof(double) * 2048;
+        }
     } else {
         c->multiwave = true;
         c->F = 1;
@@ -256,7 +280,10 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
     }
     switch (c->decoder_id) {
     case LDPC_HIP_MS_DEC:
-        if (c->multiwave) {
+        if (c->fast_m64 && c->fast_variant >= 0) {
+            if (c->fast_variant == 1) hipLaunchKernelGGL(ldpc::ms_flood_m64_kernel<false>, grid, block, c->lds_bytes, stream, a, c->fast_tab);
+            else hipLaunchKernelGGL(ldpc::ms_flood_m64_kernel<true>, grid, block, c->lds_bytes, stream, a, c->fast_tab);
+        } else if (c->multiwave) {
             auto k = ldpc::ms_flood_kernel<kRHM, kNHM, true>;
             if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
             hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
