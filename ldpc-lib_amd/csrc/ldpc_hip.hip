@@ -16,6 +16,8 @@
 #include "ldpc_frontend.hpp"
 #include "ldpc_kernels.hpp"
 #include "ldpc_ms_fast.hpp"
+#include "ldpc_ms_spec.hpp"
+#include "code_appendix_c_m64.hpp"
 #include "ldpc_sumprod.hpp"
 
 namespace {
@@ -45,6 +47,11 @@ constexpr int kRWM = 16;   // max circulants per block row (edge-sign bits per r
 
 }  // namespace
 
+// ahead-of-time instance of the code-specialised kernel for the shipped example code
+__global__ void __launch_bounds__(64, 2) ms_spec_appendix_c_m64_kernel(const ldpc_spec::SpecArgs a) {
+    ldpc_spec::ms_m64_body<ldpc_spec::CodeAppendixCM64>(a);
+}
+
 struct ldpc_hip_ctx {
     int decoder_id = 0, device = 0;
     int rh = 0, nh = 0, M = 0, N = 0, R = 0, ne = 0, hard_words = 0;
@@ -54,7 +61,9 @@ struct ldpc_hip_ctx {
     bool multiwave = false;
     size_t lds_bytes = 0;
     bool fast_m64 = false;     // flagship path: min-sum, M == 64, table in the kernel-argument segment
-    int fast_variant = 0;      // 0 = LDS fp64 atomics, 1 = read-add-write (A/B switch, LDPC_HIP_MS_VARIANT)
+    int fast_variant = 2;      // LDPC_HIP_MS_VARIANT: 2 = code-specialised (AOT/JIT) [default], 0 = table kernel with LDS
+                               // fp64 atomics, 1 = table kernel read-add-write, -1 = generic kernel
+    bool spec_aot = false;     // the opened matrix is the shipped example code: use the ahead-of-time instance
     ldpc::FastTab fast_tab;
     // device tables
     int32_t *d_row_start = nullptr, *d_col_start = nullptr;
@@ -188,7 +197,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
             c->max_rw <= ldpc::kFastSlots && all_cols_used) {
             c->fast_m64 = true;
             const char *v = getenv("LDPC_HIP_MS_VARIANT");
-            c->fast_variant = v ? atoi(v) : 0;
+            c->fast_variant = v ? atoi(v) : 2;
             std::memset(&c->fast_tab, 0, sizeof c->fast_tab);
             std::vector<char> seen(nh, 0);
             for (int j = 0; j < rh; ++j)
@@ -200,6 +209,17 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
                     c->fast_tab.pk[j][slot >> 1] |= ldpc::fast_desc(first, k, sh) << ((slot & 1) * 16);
                 }
             c->lds_bytes = sizeof(double) * 2048;
+            {   // is this the shipped example code?  (compare with the generated constexpr tables)
+                using FC = ldpc_spec::CodeAppendixCM64;
+                bool same = rh == FC::RH && nh == FC::NH;
+                for (int j = 0; same && j < rh; ++j) {
+                    same = (row_start[j + 1] - row_start[j]) == FC::RW[j];
+                    for (int e = row_start[j]; same && e < row_start[j + 1]; ++e)
+                        same = (int)(edges[e] >> 16) == FC::COL[j][e - row_start[j]] &&
+                               (int)(edges[e] & 0xffffu) == FC::SH[j][e - row_start[j]];
+                }
+                c->spec_aot = same;
+            }
         }
     } else {
         c->multiwave = true;
@@ -280,7 +300,11 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
     }
     switch (c->decoder_id) {
     case LDPC_HIP_MS_DEC:
-        if (c->fast_m64 && c->fast_variant >= 0) {
+        if (c->fast_m64 && c->fast_variant == 2 && c->spec_aot) {
+            ldpc_spec::SpecArgs sa{};
+            sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
+            hipLaunchKernelGGL(ms_spec_appendix_c_m64_kernel, grid, block, c->lds_bytes, stream, sa);
+        } else if (c->fast_m64 && c->fast_variant >= 0) {
             if (c->fast_variant == 1) hipLaunchKernelGGL(ldpc::ms_flood_m64_kernel<false>, grid, block, c->lds_bytes, stream, a, c->fast_tab);
             else hipLaunchKernelGGL(ldpc::ms_flood_m64_kernel<true>, grid, block, c->lds_bytes, stream, a, c->fast_tab);
         } else if (c->multiwave) {

@@ -1,0 +1,182 @@
+// ldpc_ms_spec.hpp -- code-specialised flooding min-sum for lifting M = 64 (one frame == one wavefront).
+//
+// The Tanner graph is a compile-time constant of this kernel: a `Code` type carries the base matrix (block row
+// weights, block column and shift of every circulant) as constexpr tables, so the instruction stream contains
+// the graph -- no descriptor loads, no scalar decode, no validity branches; a circulant's block column is the
+// immediate offset of its ds_read/ds_add, its shift an immediate add (shift 0 needs no address arithmetic at
+// all), its position in the row word an immediate.  The same source is used twice:
+//   * ahead of time for the shipped example code (SURVEY Appendix C lifted to M = 64), compiled into libldpc_hip.so;
+//   * just in time (hiprtc) at ldpc_hip_open() for any other base matrix: the host writes the `Code` struct for the
+//     opened matrix, compiles this header for gfx950 and caches the code object per matrix.
+// Algorithm, operation order and results are those of ms_flood_kernel / upstream min_sum_decod_qc_lm
+// (decoders.cpp:4554-4767): bit-identical hard decisions, iteration counts and soft values.
+//
+// See ldpc_ms_fast.hpp for the arguments behind: sign-bit tests, LDS fp64 atomics in ascending block-row order, the
+// first edge of a block column storing instead of adding, and MAX_VAL clamping folded into the min1/min2 start value.
+//
+// This header must stay self-contained (hiprtc compiles it without the rest of the tree).
+#pragma once
+
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#endif
+
+namespace ldpc_spec {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+struct SpecArgs {
+    const double *llr;   // [B][N]
+    u32 *hard;           // [B][N/32] or null
+    int *iters;          // [B] or null
+    double *soft_out;    // [B][N] or null
+    int maxiter;
+    double alpha;
+};
+
+template <int I> struct IC { static constexpr int value = I; };
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(IC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+__device__ __forceinline__ u32 hi32(double x) { return (u32)__double2hiint(x); }
+__device__ __forceinline__ u32 lo32(double x) { return (u32)__double2loint(x); }
+__device__ __forceinline__ double mk(u32 hi, u32 lo) { return __hiloint2double((int)hi, (int)lo); }
+// |mag| with the sign bit of sign_src (mag >= 0)
+__device__ __forceinline__ double signed_mag(double mag, u32 sign_src) {
+    return mk((hi32(mag) & 0x7fffffffu) | (sign_src & 0x80000000u), lo32(mag));
+}
+
+constexpr double kMaxVal = 32767.0;  // decoders.cpp:4299-4301
+
+template <class C>
+__device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
+    constexpr int RH = C::RH, NH = C::NH, N = C::NH * 64;
+    extern __shared__ double lds[];  // [N] soft / acc (fp64)
+    char *const ldsb = reinterpret_cast<char *>(lds);
+    const int lane = threadIdx.x;
+    const u32 n8 = (u32)lane * 8u;
+    const double alpha = a.alpha;
+    const long long fr = blockIdx.x;  // one wave per frame
+
+    // LDS byte offset (inside a block column) of variable (lane + shift) mod 64.  `base` is an opaque per-row copy of
+    // n8: it keeps the compiler from hoisting/CSE-ing the ~40 distinct rotated addresses out of the iteration loop
+    // into long-lived VGPRs (that costs more in spills than the two integer ops per non-zero shift it saves).
+    auto rot = [&](u32 base, auto S) -> u32 {
+        constexpr int c = decltype(S)::value;
+        if constexpr (c == 0) return base;
+        else return (base + 8u * (u32)c) & 511u;
+    };
+
+    double y[NH];
+    static_for<0, NH>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        y[k] = a.llr[fr * N + k * 64 + lane] + 0.0;  // canonicalise -0.0 (see ldpc_kernels.hpp)
+    });
+
+    double m1[RH], m2[RH];
+    u32 meta[RH];  // [15:0] v2c sign bit per slot, [23:16] slot of the min1 edge
+    static_for<0, RH>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        m1[j] = 0.0; m2[j] = 0.0; meta[j] = 0u;   // :4579-4596
+    });
+
+    int res = -a.maxiter;
+    for (int iter = 0; iter < a.maxiter; ++iter) {
+        // ---------------- STATE1 (:4633-4667): acc[v] = sum of c2v, ascending block row
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            u32 mt = meta[j], nb = n8;
+            // A volatile asm is ordered with the LDS operations around it, and everything this block row computes
+            // depends on its outputs: the row's ALU work therefore stays between the previous row's LDS operations
+            // and its own (otherwise instruction selection emits all 112 c2v computations first and spills them).
+            asm volatile("" : "+v"(mt), "+v"(nb));
+            const u32 pos = mt >> 16;
+            const u32 W = (mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u));  // bit s = sign of the c2v on slot s
+            static_for<0, C::RW[j]>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                constexpr int k = C::COL[j][s];
+                const double aa = (pos == (u32)s) ? m2[j] : m1[j];
+                const double cv = signed_mag(aa, W << (31 - s));
+                double *p = reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + k * 512);
+                if constexpr (C::FIRST[j][s]) *p = cv;
+                else __hip_atomic_fetch_add(p, cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            });
+            __builtin_amdgcn_sched_barrier(0);  // one block row at a time: keeps the live set (and the spills) small
+        });
+        // ---------------- STATE2 (:4670-4685): soft = y + acc*alpha (two roundings)
+        static_for<0, NH>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            double *p = reinterpret_cast<double *>(ldsb + n8 + k * 512);
+            const double pr = *p * alpha;
+            *p = y[k] + pr;
+            if constexpr (k % 8 == 7) __builtin_amdgcn_sched_barrier(0);  // 8 columns in flight, not 32 (VGPR budget)
+        });
+        // ---------------- STATE3 (:4690-4755)
+        u32 failw = 0;
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int RW = C::RW[j];
+            u32 mt = meta[j];
+            // opaque: otherwise the compiler keeps STATE1's 112 select masks and shifted sign words alive across the
+            // whole iteration to reuse them here (SGPR + VGPR spills to scratch); recomputing costs 3 ops per edge.
+            asm volatile("" : "+v"(mt));
+            const u32 pos = mt >> 16;
+            const u32 W = (mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u));
+            double a1 = m1[j] * alpha, a2 = m2[j] * alpha;
+            asm volatile("" : "+v"(a1), "+v"(a2));  // two products per ROW, not one per edge
+            double nm1 = kMaxVal, nm2 = kMaxVal;    // start value == the MAX_VAL clamp of :4730
+            u32 npos = 0, nS = 0, sy = 0;
+            u32 nb = n8;
+            asm volatile("" : "+v"(nb));
+            double r[RW];
+            static_for<0, RW>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                r[s] = *reinterpret_cast<const double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * 512);
+            });
+            static_for<0, RW>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                sy ^= hi32(r[s]);
+                const double aa = (pos == (u32)s) ? a2 : a1;
+                const double x = signed_mag(aa, W << (31 - s));
+                const double tt = r[s] - x;              // v2c
+                nS |= (hi32(tt) >> 31) << s;
+                const double v = fabs(tt);
+                const bool c1 = v < nm1;                 // strict: the first minimum keeps the position
+                nm2 = fmin(fmax(v, nm1), nm2);           // = c1 ? nm1 : min(v, nm2)
+                npos = c1 ? (u32)s : npos;
+                nm1 = fmin(v, nm1);
+            });
+            failw |= sy;
+            m1[j] = nm1; m2[j] = nm2; meta[j] = nS | (npos << 16);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (__ballot((failw >> 31) != 0) == 0ull) { res = iter + 1; break; }  // :4761-4766
+    }
+
+    // ---------------- outputs
+    if (lane == 0 && a.iters) a.iters[fr] = res;
+    if (a.hard) {
+        u64 mine = 0ull;
+        static_for<0, NH>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            const u64 b = __ballot((hi32(*reinterpret_cast<const double *>(ldsb + n8 + k * 512)) >> 31) != 0);
+            if (lane == k) mine = b;
+        });
+        // block column k = variables 64k..64k+63 = packed words 2k, 2k+1
+        if (lane < NH) reinterpret_cast<u64 *>(a.hard + fr * (N / 32))[lane] = mine;
+    }
+    if (a.soft_out) {
+        static_for<0, NH>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            a.soft_out[fr * N + k * 64 + lane] = *reinterpret_cast<const double *>(ldsb + n8 + k * 512);
+        });
+    }
+}
+
+}  // namespace ldpc_spec
