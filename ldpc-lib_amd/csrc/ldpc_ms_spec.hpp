@@ -73,14 +73,10 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
         else return (base + 8u * (u32)c) & 511u;
     };
 
-    double y[NH];
-    static_for<0, NH>([&](auto K) {
-        constexpr int k = decltype(K)::value;
-        y[k] = a.llr[fr * N + k * 64 + lane] + 0.0;  // canonicalise -0.0 (see ldpc_kernels.hpp)
-    });
+    const double *const yrow = a.llr + fr * N + lane;  // this frame's channel LLRs, variable (k, lane) at yrow[64 k]
 
     double m1[RH], m2[RH];
-    u32 meta[RH];  // [15:0] v2c sign bit per slot, [23:16] slot of the min1 edge
+    u32 meta[RH];  // [15:0] v2c sign bits, slot s of a row of weight RW on bit RW-1-s; [23:16] slot of the min1 edge
     static_for<0, RH>([&](auto J) {
         constexpr int j = decltype(J)::value;
         m1[j] = 0.0; m2[j] = 0.0; meta[j] = 0u;   // :4579-4596
@@ -88,6 +84,16 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
 
     int res = -a.maxiter;
     for (int iter = 0; iter < a.maxiter; ++iter) {
+        // The channel LLRs are needed only in STATE2.  Instead of pinning 64 VGPRs for the whole kernel they are
+        // re-read every iteration (16 KiB per frame: L2 / Infinity-Cache hits after the first pass) right here, so the
+        // loads fly under STATE1's ALU work, and the registers are free again during STATE3 where pressure peaks.
+        double y[NH];
+        const double *yp = yrow;
+        asm volatile("" : "+v"(yp));  // opaque per iteration: the loads must not be hoisted out of the loop again
+        static_for<0, NH>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            y[k] = yp[k * 64];
+        });
         // ---------------- STATE1 (:4633-4667): acc[v] = sum of c2v, ascending block row
         static_for<0, RH>([&](auto J) {
             constexpr int j = decltype(J)::value;
@@ -101,8 +107,9 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
             static_for<0, C::RW[j]>([&](auto S) {
                 constexpr int s = decltype(S)::value;
                 constexpr int k = C::COL[j][s];
+                constexpr int bit = C::RW[j] - 1 - s;
                 const double aa = (pos == (u32)s) ? m2[j] : m1[j];
-                const double cv = signed_mag(aa, W << (31 - s));
+                const double cv = signed_mag(aa, W << (31 - bit));
                 double *p = reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + k * 512);
                 if constexpr (C::FIRST[j][s]) *p = cv;
                 else __hip_atomic_fetch_add(p, cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -114,7 +121,7 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
             constexpr int k = decltype(K)::value;
             double *p = reinterpret_cast<double *>(ldsb + n8 + k * 512);
             const double pr = *p * alpha;
-            *p = y[k] + pr;
+            *p = (y[k] + 0.0) + pr;   // + 0.0 canonicalises a -0.0 input (see ldpc_kernels.hpp); exact otherwise
             if constexpr (k % 8 == 7) __builtin_amdgcn_sched_barrier(0);  // 8 columns in flight, not 32 (VGPR budget)
         });
         // ---------------- STATE3 (:4690-4755)
@@ -143,9 +150,9 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
                 constexpr int s = decltype(S)::value;
                 sy ^= hi32(r[s]);
                 const double aa = (pos == (u32)s) ? a2 : a1;
-                const double x = signed_mag(aa, W << (31 - s));
+                const double x = signed_mag(aa, W << (31 - (RW - 1 - s)));
                 const double tt = r[s] - x;              // v2c
-                nS |= (hi32(tt) >> 31) << s;
+                nS = __builtin_amdgcn_alignbit(nS, hi32(tt), 31);  // (nS << 1) | sign(tt): slot s lands on bit RW-1-s
                 const double v = fabs(tt);
                 const bool c1 = v < nm1;                 // strict: the first minimum keeps the position
                 nm2 = fmin(fmax(v, nm1), nm2);           // = c1 ? nm1 : min(v, nm2)
