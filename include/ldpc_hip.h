@@ -57,6 +57,8 @@ int ldpc_hip_n(const ldpc_hip_ctx *ctx);          /* N = nh*M */
 int ldpc_hip_r(const ldpc_hip_ctx *ctx);          /* R = rh*M */
 int ldpc_hip_edges(const ldpc_hip_ctx *ctx);      /* non-empty circulants */
 int ldpc_hip_hard_words(const ldpc_hip_ctx *ctx); /* ceil(N/32): uint32 words per frame of packed hard bits */
+/* Name of the decode kernel this context launches (code-specialised AOT / hiprtc instance, table-driven, generic). */
+const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *ctx);
 
 /* Batched replacement of the decoder entry points (decoders.h:297,299,304; dispatch bp_simulation.cpp:716-729):
  *   MS_DEC : min_sum_decod_qc_lm(st, y, decword, maxiter, decision, alpha)
@@ -103,7 +105,7 @@ int ldpc_hip_qam_demod_dev(int Q, double T, double sigma, const double *d_x, lon
 /* Error accounting, replaces bp_simulation.cpp:731-759,805-810 for the all-zero codeword.
  *   d_frame_info [B] int32 out (or NULL): number of wrong information bits (index >= R) of the frame, with bit 30
  *                set when the frame has any wrong bit at all (so 0 == frame correct)
- *   d_counters [4] uint64 in/out (accumulated with atomics; caller zeroes): nse, nde, nue, frames */
+ *   d_counters [5] uint64 in/out (accumulated with atomics; caller zeroes): nse, nde, nue, frames, sum |iters| */
 int ldpc_hip_count_errors_dev(ldpc_hip_ctx *ctx, const uint32_t *d_hard, const int32_t *d_iters, long long B,
                               int32_t *d_frame_info, unsigned long long *d_counters, void *stream);
 

@@ -54,6 +54,9 @@ def load_library():
     # pulls in /opt/rocm's copy and the second runtime then finds no device.
     try:
         import torch  # noqa: F401
+        rtc = os.path.join(os.path.dirname(torch.__file__), "lib", "libhiprtc.so")
+        if os.path.exists(rtc):  # JIT with the hiprtc that matches the HIP runtime torch brought into this process
+            os.environ.setdefault("LDPC_HIP_HIPRTC_PATH", rtc)
     except ImportError:
         pass
     path = library_path()
@@ -70,6 +73,8 @@ def load_library():
     lib.ldpc_hip_close.restype = None
     for f in ("ldpc_hip_n", "ldpc_hip_r", "ldpc_hip_edges", "ldpc_hip_hard_words"):
         getattr(lib, f).argtypes = [vp]
+    lib.ldpc_hip_kernel_name.argtypes = [vp]
+    lib.ldpc_hip_kernel_name.restype = C.c_char_p
     lib.ldpc_hip_decode_dev.argtypes = [vp, vp, i64, i32, f64, vp, vp, vp, vp]
     lib.ldpc_hip_decode_host.argtypes = [vp, vp, i64, i32, i32, f64, vp, vp, i32]
     lib.ldpc_hip_awgn_llr_dev.argtypes = [vp, f64, i32, i32, u64, i64, i64, vp, vp]
@@ -113,6 +118,7 @@ class LdpcHip:
         self.R = self.lib.ldpc_hip_r(h)
         self.edges = self.lib.ldpc_hip_edges(h)
         self.hard_words = self.lib.ldpc_hip_hard_words(h)
+        self.kernel_name = self.lib.ldpc_hip_kernel_name(h).decode()
 
     def close(self):
         if getattr(self, "h", None):

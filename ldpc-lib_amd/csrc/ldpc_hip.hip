@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "ldpc_frontend.hpp"
+#include "ldpc_jit.hpp"
 #include "ldpc_kernels.hpp"
 #include "ldpc_ms_fast.hpp"
 #include "ldpc_ms_spec.hpp"
@@ -64,6 +65,8 @@ struct ldpc_hip_ctx {
     int fast_variant = 2;      // LDPC_HIP_MS_VARIANT: 2 = code-specialised (AOT/JIT) [default], 0 = table kernel with LDS
                                // fp64 atomics, 1 = table kernel read-add-write, -1 = generic kernel
     bool spec_aot = false;     // the opened matrix is the shipped example code: use the ahead-of-time instance
+    const ldpc_jit::Kernel *jit = nullptr;  // code-specialised instance compiled at open() for any other matrix
+    std::string kernel_name;   // which decode kernel this context launches (ldpc_hip_kernel_name)
     ldpc::FastTab fast_tab;
     // device tables
     int32_t *d_row_start = nullptr, *d_col_start = nullptr;
@@ -193,11 +196,15 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
         c->lds_bytes = sizeof(double) * (size_t)c->N * c->F + 16;
         bool all_cols_used = true;
         for (int k = 0; k < nh; ++k) all_cols_used = all_cols_used && (col_start[k + 1] > col_start[k]);
-        if (decoder_id == LDPC_HIP_MS_DEC && M == 64 && rh <= ldpc::kFastRows && nh <= ldpc::kFastCols &&
-            c->max_rw <= ldpc::kFastSlots && all_cols_used) {
+        const char *venv = getenv("LDPC_HIP_MS_VARIANT");
+        c->fast_variant = venv ? atoi(venv) : 2;
+        c->kernel_name = decoder_id == LDPC_HIP_MS_DEC ? (c->multiwave ? "ms_flood_kernel<multiwave>" : "ms_flood_kernel")
+                                                       : (c->multiwave ? "lms_layered_kernel<multiwave>" : "lms_layered_kernel");
+        const bool m64 = decoder_id == LDPC_HIP_MS_DEC && M == 64 && rh <= ldpc::kFastRows && nh <= ldpc::kFastCols && all_cols_used;
+        if (m64 && c->max_rw <= ldpc::kFastSlots && c->fast_variant >= 0) {
+            // table-driven M = 64 kernel (always available)
             c->fast_m64 = true;
-            const char *v = getenv("LDPC_HIP_MS_VARIANT");
-            c->fast_variant = v ? atoi(v) : 2;
+            c->kernel_name = c->fast_variant == 1 ? "ms_flood_m64_kernel<rmw>" : "ms_flood_m64_kernel<atomic>";
             std::memset(&c->fast_tab, 0, sizeof c->fast_tab);
             std::vector<char> seen(nh, 0);
             for (int j = 0; j < rh; ++j)
@@ -209,16 +216,36 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
                     c->fast_tab.pk[j][slot >> 1] |= ldpc::fast_desc(first, k, sh) << ((slot & 1) * 16);
                 }
             c->lds_bytes = sizeof(double) * 2048;
-            {   // is this the shipped example code?  (compare with the generated constexpr tables)
-                using FC = ldpc_spec::CodeAppendixCM64;
-                bool same = rh == FC::RH && nh == FC::NH;
-                for (int j = 0; same && j < rh; ++j) {
-                    same = (row_start[j + 1] - row_start[j]) == FC::RW[j];
-                    for (int e = row_start[j]; same && e < row_start[j + 1]; ++e)
-                        same = (int)(edges[e] >> 16) == FC::COL[j][e - row_start[j]] &&
-                               (int)(edges[e] & 0xffffu) == FC::SH[j][e - row_start[j]];
+        }
+        if (m64 && c->max_rw <= 16 && c->fast_variant == 2) {
+            // code-specialised kernel: ahead-of-time instance for the shipped example code, hiprtc for anything else
+            using FC = ldpc_spec::CodeAppendixCM64;
+            bool same = rh == FC::RH && nh == FC::NH;
+            for (int j = 0; same && j < rh; ++j) {
+                same = (row_start[j + 1] - row_start[j]) == FC::RW[j];
+                for (int e = row_start[j]; same && e < row_start[j + 1]; ++e)
+                    same = (int)(edges[e] >> 16) == FC::COL[j][e - row_start[j]] &&
+                           (int)(edges[e] & 0xffffu) == FC::SH[j][e - row_start[j]];
+            }
+            const char *jenv = getenv("LDPC_HIP_JIT");
+            if (same) {
+                c->spec_aot = true;
+                c->kernel_name = "ms_spec_appendix_c_m64_kernel (ahead of time)";
+                c->lds_bytes = sizeof(double) * (size_t)c->N;
+            } else if (!jenv || atoi(jenv) != 0) {
+                std::vector<std::vector<std::pair<int, int>>> rows(rh);
+                for (int j = 0; j < rh; ++j)
+                    for (int e = row_start[j]; e < row_start[j + 1]; ++e)
+                        rows[j].emplace_back((int)(edges[e] >> 16), (int)(edges[e] & 0xffffu));
+                std::string jerr;
+                c->jit = ldpc_jit::get_ms_m64(device, rows, nh, jerr);
+                if (c->jit) {
+                    c->kernel_name = "ms_spec_jit (hiprtc)";
+                    c->lds_bytes = sizeof(double) * (size_t)c->N;
+                } else {
+                    fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", jerr.c_str(),
+                            c->kernel_name.c_str());
                 }
-                c->spec_aot = same;
             }
         }
     } else {
@@ -226,6 +253,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
         c->F = 1;
         c->threads = 256;
         c->lds_bytes = ldpc::sp_lds_bytes(c->ne, M, c->R, c->N);
+        c->kernel_name = "sp_flood_kernel";
         if (c->N > ldpc::kSpNVM * c->threads) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "sum-product: N=%d > %d", c->N, ldpc::kSpNVM * c->threads); }
     }
     if (c->lds_bytes > 160 * 1024) {
@@ -272,6 +300,7 @@ int ldpc_hip_n(const ldpc_hip_ctx *c) { return c ? c->N : 0; }
 int ldpc_hip_r(const ldpc_hip_ctx *c) { return c ? c->R : 0; }
 int ldpc_hip_edges(const ldpc_hip_ctx *c) { return c ? c->ne : 0; }
 int ldpc_hip_hard_words(const ldpc_hip_ctx *c) { return c ? c->hard_words : 0; }
+const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *c) { return c ? c->kernel_name.c_str() : ""; }
 
 int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int maxiter, double alpha,
                         uint32_t *d_hard, int32_t *d_iters, double *d_soft, void *stream_) {
@@ -300,11 +329,16 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
     }
     switch (c->decoder_id) {
     case LDPC_HIP_MS_DEC:
-        if (c->fast_m64 && c->fast_variant == 2 && c->spec_aot) {
+        if (c->spec_aot || c->jit) {
             ldpc_spec::SpecArgs sa{};
             sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
-            hipLaunchKernelGGL(ms_spec_appendix_c_m64_kernel, grid, block, c->lds_bytes, stream, sa);
-        } else if (c->fast_m64 && c->fast_variant >= 0) {
+            if (c->spec_aot) {
+                hipLaunchKernelGGL(ms_spec_appendix_c_m64_kernel, grid, block, c->lds_bytes, stream, sa);
+            } else {
+                void *kargs[] = {&sa};
+                HIP_TRY(hipModuleLaunchKernel(c->jit->fn, grid.x, 1, 1, 64, 1, 1, (unsigned)c->lds_bytes, stream, kargs, nullptr));
+            }
+        } else if (c->fast_m64) {
             if (c->fast_variant == 1) hipLaunchKernelGGL(ldpc::ms_flood_m64_kernel<false>, grid, block, c->lds_bytes, stream, a, c->fast_tab);
             else hipLaunchKernelGGL(ldpc::ms_flood_m64_kernel<true>, grid, block, c->lds_bytes, stream, a, c->fast_tab);
         } else if (c->multiwave) {

@@ -1,0 +1,157 @@
+// ldpc_jit.hpp -- just-in-time instances of the code-specialised min-sum kernel (ldpc_ms_spec.hpp) via hiprtc.
+//
+// ldpc_hip_open() of an M = 64 min-sum code that is not the ahead-of-time instance writes the constexpr `Code`
+// tables of the opened base matrix as C++ source, compiles ldpc_ms_spec.hpp against them for gfx950 and keeps the
+// code object in a per-process cache keyed by (device, base matrix).  hiprtc is loaded lazily with dlopen; when it
+// (or the header next to the library) is unavailable the caller keeps using the table-driven kernel
+// (ldpc_ms_fast.hpp) -- still a HIP kernel, never a CPU path.
+#pragma once
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace ldpc_jit {
+
+struct Kernel {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+};
+
+// minimal hiprtc surface (resolved with dlsym so that libldpc_hip.so has no link-time dependency on it)
+typedef struct _hiprtcProgram *hiprtcProgram;
+struct Rtc {
+    void *lib = nullptr;
+    int (*CreateProgram)(hiprtcProgram *, const char *, const char *, int, const char **, const char **) = nullptr;
+    int (*CompileProgram)(hiprtcProgram, int, const char **) = nullptr;
+    int (*GetCodeSize)(hiprtcProgram, size_t *) = nullptr;
+    int (*GetCode)(hiprtcProgram, char *) = nullptr;
+    int (*GetProgramLogSize)(hiprtcProgram, size_t *) = nullptr;
+    int (*GetProgramLog)(hiprtcProgram, char *) = nullptr;
+    int (*DestroyProgram)(hiprtcProgram *) = nullptr;
+};
+
+inline Rtc *rtc(std::string &err) {
+    static Rtc r;
+    static bool tried = false;
+    if (tried) { if (!r.lib) err = "hiprtc not available"; return r.lib ? &r : nullptr; }
+    tried = true;
+    std::vector<std::string> names;
+    if (const char *p = getenv("LDPC_HIP_HIPRTC_PATH")) names.push_back(p);
+    names.push_back("libhiprtc.so");
+    names.push_back("libhiprtc.so.7");
+    names.push_back("/opt/rocm/lib/libhiprtc.so");
+    for (const auto &n : names) {
+        r.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) { err = "dlopen(libhiprtc.so) failed"; return nullptr; }
+#define LDPC_RTC_SYM(f)                                                         \
+    r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.lib, "hiprtc" #f));           \
+    if (!r.f) { err = "hiprtc" #f " missing"; r.lib = nullptr; return nullptr; }
+    LDPC_RTC_SYM(CreateProgram) LDPC_RTC_SYM(CompileProgram) LDPC_RTC_SYM(GetCodeSize) LDPC_RTC_SYM(GetCode)
+    LDPC_RTC_SYM(GetProgramLogSize) LDPC_RTC_SYM(GetProgramLog) LDPC_RTC_SYM(DestroyProgram)
+#undef LDPC_RTC_SYM
+    return &r;
+}
+
+// `struct Code` for ms_m64_body<>: rows[j] = list of (block column, shift) in ascending column order
+inline std::string code_struct(const std::vector<std::vector<std::pair<int, int>>> &rows, int nh) {
+    const int rh = (int)rows.size();
+    size_t wmax = 1;
+    for (auto &r : rows) wmax = r.size() > wmax ? r.size() : wmax;
+    std::vector<char> seen(nh, 0);
+    std::ostringstream col, sh, fi, rw;
+    for (int j = 0; j < rh; ++j) {
+        col << (j ? ", {" : "{"); sh << (j ? ", {" : "{"); fi << (j ? ", {" : "{");
+        rw << (j ? ", " : "") << rows[j].size();
+        for (size_t s = 0; s < wmax; ++s) {
+            const bool has = s < rows[j].size();
+            const int k = has ? rows[j][s].first : 0, c = has ? rows[j][s].second : 0;
+            int first = 0;
+            if (has && !seen[k]) { first = 1; seen[k] = 1; }
+            col << (s ? ", " : "") << k; sh << (s ? ", " : "") << c; fi << (s ? ", " : "") << first;
+        }
+        col << "}"; sh << "}"; fi << "}";
+    }
+    std::ostringstream o;
+    o << "struct Code {\n"
+      << "    static constexpr int RH = " << rh << ", NH = " << nh << ", WMAX = " << wmax << ";\n"
+      << "    static constexpr int RW[" << rh << "] = {" << rw.str() << "};\n"
+      << "    static constexpr int COL[" << rh << "][" << wmax << "] = {" << col.str() << "};\n"
+      << "    static constexpr int SH[" << rh << "][" << wmax << "] = {" << sh.str() << "};\n"
+      << "    static constexpr int FIRST[" << rh << "][" << wmax << "] = {" << fi.str() << "};\n"
+      << "};\n";
+    return o.str();
+}
+
+inline std::string this_library_dir() {
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<void *>(&this_library_dir), &info) || !info.dli_fname) return ".";
+    std::string p = info.dli_fname;
+    const size_t k = p.find_last_of('/');
+    return k == std::string::npos ? "." : p.substr(0, k);
+}
+
+// Returns the cached or freshly compiled kernel for (device, rows); nullptr + err on failure.
+inline const Kernel *get_ms_m64(int device, const std::vector<std::vector<std::pair<int, int>>> &rows, int nh,
+                                std::string &err) {
+    static std::mutex mu;
+    static std::map<std::string, Kernel> cache;
+    const std::string code = code_struct(rows, nh);
+    const std::string key = std::to_string(device) + "|" + code;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return &it->second;
+
+    Rtc *r = rtc(err);
+    if (!r) return nullptr;
+    const std::string hdr_path = this_library_dir() + "/csrc/ldpc_ms_spec.hpp";
+    std::ifstream hf(hdr_path);
+    if (!hf) { err = "cannot read " + hdr_path; return nullptr; }
+    std::stringstream hs;
+    hs << hf.rdbuf();
+    const std::string hdr = hs.str();
+    const std::string src = "#include \"ldpc_ms_spec.hpp\"\nnamespace {\n" + code +
+                            "}\nextern \"C\" __global__ void __launch_bounds__(64, 2) ms_spec_jit(const ldpc_spec::SpecArgs a) {\n"
+                            "    ldpc_spec::ms_m64_body<Code>(a);\n}\n";
+    hiprtcProgram prog = nullptr;
+    const char *hdr_src[] = {hdr.c_str()};
+    const char *hdr_name[] = {"ldpc_ms_spec.hpp"};
+    if (r->CreateProgram(&prog, src.c_str(), "ldpc_ms_spec_jit.hip", 1, hdr_src, hdr_name) != 0) { err = "hiprtcCreateProgram failed"; return nullptr; }
+    // -ffp-contract=off is part of the numerics contract (two roundings in y + s*alpha)
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+    const int rc = r->CompileProgram(prog, 4, opts);
+    if (rc != 0) {
+        size_t n = 0;
+        r->GetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) r->GetProgramLog(prog, &log[0]);
+        err = "hiprtcCompileProgram failed: " + log.substr(0, 400);
+        r->DestroyProgram(&prog);
+        return nullptr;
+    }
+    size_t n = 0;
+    r->GetCodeSize(prog, &n);
+    std::vector<char> bin(n);
+    r->GetCode(prog, bin.data());
+    r->DestroyProgram(&prog);
+    Kernel k;
+    if (hipSetDevice(device) != hipSuccess || hipModuleLoadData(&k.mod, bin.data()) != hipSuccess ||
+        hipModuleGetFunction(&k.fn, k.mod, "ms_spec_jit") != hipSuccess) {
+        err = std::string("loading the JIT code object failed: ") + hipGetErrorString(hipGetLastError());
+        return nullptr;
+    }
+    auto ins = cache.emplace(key, k);
+    return &ins.first->second;
+}
+
+}  // namespace ldpc_jit

@@ -256,3 +256,35 @@ def test_qam_frontend(L, torch):
         hard, iters, _ = dec.decode(llr, 50)
         assert (llr > 0).double().mean().item() > 0.9
         assert (iters > 0).double().mean().item() > 0.95
+
+
+def _other_m64_code():
+    """A different (2048,1024)-shaped code: same protograph, other circulant shifts (so not the ahead-of-time instance)."""
+    H = relift(load_base_matrix(), 64)
+    H2 = H.copy()
+    H2[H > 0] = (H[H > 0] * 7 + 3) % 64
+    return H2
+
+
+@pytest.mark.parametrize("variant,expect", [("2", "jit"), ("0", "m64_kernel<atomic>"), ("1", "m64_kernel<rmw>"), ("-1", "ms_flood_kernel")])
+def test_every_min_sum_kernel_tier_is_bit_exact(L, torch, monkeypatch, variant, expect):
+    """The code-specialised hiprtc instance (any base matrix), the table-driven M=64 kernel (atomic and read-add-write
+    accumulation) and the generic kernel must all reproduce the oracle bit for bit."""
+    monkeypatch.setenv("LDPC_HIP_MS_VARIANT", variant)
+    H2 = _other_m64_code()
+    llr = np.concatenate([awgn_llr(H2, 64, s, 40 + i, 40) for i, s in enumerate((1.0, 1.6, 2.4))])
+    o = Oracle(H2, 64)
+    d_ref, it_ref, _ = o.decode(MS_DEC, llr, 50, 0)
+    s_ref, _, _ = o.decode(MS_DEC, llr, 50, 1)
+    with L.LdpcHip(MS_DEC, H2, 64) as dec:
+        assert expect in dec.kernel_name, dec.kernel_name
+        hard, iters, soft = dec.decode(torch.from_numpy(llr).cuda(), 50, want_soft=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(iters.cpu().numpy(), it_ref)
+        assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
+        assert np.array_equal(soft.cpu().numpy(), s_ref)
+
+
+def test_flagship_code_uses_the_ahead_of_time_instance(L):
+    with L.LdpcHip(MS_DEC, relift(load_base_matrix(), 64), 64) as dec:
+        assert "ahead of time" in dec.kernel_name
