@@ -1,0 +1,164 @@
+/*
+ * ldpc/bp_simulation.h -- the Monte-Carlo harness of upstream's bp_simulation.h:9-27 / bp_simulation.cpp:305-841
+ * on the MI355X batch decoder, in EXACT-REPLAY mode: the channel noise comes from the same std::mt19937 in the same
+ * draw order as upstream (commons_portable.cpp:138-178, bp_simulation.cpp:512,600-611), frames are decoded in
+ * GPU batches, and upstream's sequential stopping rule (bp_simulation.cpp:591,820) is replayed over the ordered
+ * per-frame results.  On an early stop the generator is rolled back and re-advanced so that it is left exactly where
+ * upstream's frame-by-frame loop leaves it (later callers draw from it: main_good_code_search.cpp:316).
+ * Result, counters and generator state are identical to upstream's for q_mod == 2, modulation SKIP/QAM4,
+ * permutation_type 0 (the only mode the shipped configurations use, files/default_constants.jsonx:6).
+ *
+ *   ldpc::bp_simulation_t<Mat, Env>()  generic over the matrix type (needs n_rows(), n_cols(), operator()(i,j))
+ *                                      and over the environment that owns the generator (see RngEnv below);
+ *   ldpc::bp_simulation()              standalone: ldpc::Matrix + the library's own generator (ldpc::reset_random).
+ * The drop-in definition of upstream's exact `bp_simulation(int, matrix<int> const&, matrix<int>&, ...)` symbol is
+ * csrc/compat/bp_simulation_dropin.cpp (compiled inside the upstream tree).
+ */
+#ifndef LDPC_COMPAT_BP_SIMULATION_H_
+#define LDPC_COMPAT_BP_SIMULATION_H_
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <utility>
+#include <vector>
+
+#include "ldpc_hip.h"
+
+namespace ldpc {
+
+enum { MODULATION_SKIP_ = 0, MODULATION_QAM4_ = 1 };  // modulation.h:4-11
+enum { DEC_DECISION_HARD = 0 };                        // decoders.h:7 DEC_DECISION
+
+struct Matrix {  // minimal stand-in for upstream's matrix<int> (data_structures.h:11-57)
+    std::vector<int> v;
+    int rows = 0, cols = 0;
+    Matrix() {}
+    Matrix(int r, int c, int init = 0) : v((size_t)r * c, init), rows(r), cols(c) {}
+    int n_rows() const { return rows; }
+    int n_cols() const { return cols; }
+    int &operator()(int r, int c) { return v[(size_t)r * cols + c]; }
+    int const &operator()(int r, int c) const { return v[(size_t)r * cols + c]; }
+};
+
+// The library's own generator with upstream's contract (commons_portable.cpp:138-178): one global mt19937, seeded
+// from initial_random_seed at the first draw after reset_random(); a FRESH distribution object per call.
+extern int initial_random_seed;
+void reset_random();
+std::mt19937 &random_generator();  // seeded on demand
+int next_random_int(int min_inclusive, int max_exclusive);
+double next_random_gaussian();
+
+struct OwnRngEnv {
+    static std::mt19937 &generator() { return random_generator(); }
+    static double gaussian() { return next_random_gaussian(); }
+    // bp_simulation.cpp:512 -> random_codeword() :142-191 draws (nh-rh)*M values of next_random_int(0,2) (:160-162);
+    // the codeword itself is overwritten with zeros afterwards (:568), so only the draws matter here.
+    template <class Mat>
+    static void burn_codeword_draws(Mat const &H, int M) {
+        for (long long i = 0, n = (long long)(H.n_cols() - H.n_rows()) * M; i < n; ++i) (void)next_random_int(0, 2);
+    }
+    [[noreturn]] static void fail(const char *msg) { fprintf(stderr, "%s\n", msg); exit(1); }  // die()
+};
+
+struct SimCounters { long long nse = 0, nde = 0, nue = 0, experiment = 0, sum_abs_iters = 0; };
+
+template <class Mat, class Env>
+std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_length, int max_iterations,
+                                          int n_frame_errors, int n_experiments, double snr,
+                                          double reference_frame_error, int decoder_type, int modulation_type,
+                                          int permutation_type, int punctured_blocks, int show_process,
+                                          SimCounters *counters_out = nullptr, int device = 0, long long max_batch = 4096) {
+    if (q_mod != 2) Env::fail("bp_simulation: only binary codes (q_mod == 2) are built in ldpc-lib_amd");
+    if (permutation_type != 0) Env::fail("bp_simulation: only permutation_type 0 (identity) is built in ldpc-lib_amd");
+    if (modulation_type != MODULATION_SKIP_ && modulation_type != MODULATION_QAM4_)
+        Env::fail("bp_simulation: exact-replay mode supports MODULATION_SKIP and MODULATION_QAM4 (upstream's QAM16+ wiring "
+                  "is broken, SURVEY Appendix B Q5/Q6; use the device-side chain ldpc_hip_awgn_qam16_llr_dev)");
+    const int b = H.n_rows(), c = H.n_cols(), M = tailbite_length;
+    const int r = b * M, n = c * M;
+
+    std::vector<int16_t> hd((size_t)b * c);
+    for (int i = 0; i < b; ++i) for (int j = 0; j < c; ++j) hd[(size_t)i * c + j] = (int16_t)H(i, j);  // :359-361
+    ldpc_hip_ctx *ctx = nullptr;
+    if (ldpc_hip_open(decoder_type, b, c, M, hd.data(), device, &ctx) != 0) Env::fail(ldpc_hip_last_error());  // :353-355
+
+    int out_type;  // :451-466
+    switch (decoder_type) {
+    case LDPC_HIP_SP_DEC: out_type = 1; break;
+    case LDPC_HIP_MS_DEC: case LDPC_HIP_LMS_DEC: out_type = 0; break;
+    default: out_type = 0; Env::fail("Unknown decoder type");
+    }
+    const int QAM = modulation_type == MODULATION_SKIP_ ? 1 : 4, halfmlog = 1;                  // :405-406
+    const double bitrate = (double)(c - b) / (c - punctured_blocks);                             // :444
+    const double sigma = std::sqrt(std::pow(10, -snr / 10) / 2 / bitrate);                       // :445
+    const double norm_factor = 2.0 * (QAM - 1.0) / 3.0;                                          // :447
+    const double sigmaQAM = std::sqrt(std::pow(10., -snr / 10.) / (2 * bitrate * halfmlog * 2) * norm_factor);  // :449
+    const double sg = modulation_type == MODULATION_SKIP_ ? sigma : sigmaQAM;
+
+    Env::burn_codeword_draws(H, M);  // :512
+
+    long long nse = 0, nue = 0, nde = 0, experiment = 0, sum_abs_iters = 0;
+    std::vector<double> llr, decword;
+    std::vector<int32_t> iters;
+    long long batch = 64;
+    bool stop = false;
+    while (!stop && nde < n_frame_errors && experiment <= n_experiments) {                      // :591
+        const long long room = (long long)n_experiments + 1 - experiment;
+        const long long B = batch < room ? batch : room;
+        llr.resize((size_t)B * n); decword.resize((size_t)B * n); iters.resize((size_t)B);
+        const std::mt19937 snapshot = Env::generator();
+        for (long long f = 0; f < B; ++f) {
+            double *y = llr.data() + (size_t)f * n;
+            for (int i = 0; i < n; ++i) {                                                       // :601-611
+                const double noise = Env::gaussian();
+                y[i] = -2.0 * (sg * noise + 2.0 * 0.0 - 1.0) / (sg * sg);                         // codeword == 0 (:568)
+            }
+            const double init_val = out_type == 1 ? 0 : 0.5;                                     // :700 (sic)
+            const int plen = M * punctured_blocks, pstart = n - plen;
+            for (int i = pstart; i < pstart + plen; ++i) y[i] = init_val;                        // :702-709
+        }
+        if (ldpc_hip_decode_host(ctx, llr.data(), B, max_iterations, DEC_DECISION_HARD, 0.8 /*MS_ALPHA*/, decword.data(),
+                                 iters.data(), 0) != 0)
+            Env::fail(ldpc_hip_last_error());
+        long long used = 0;
+        for (long long f = 0; f < B; ++f) {                                                     // ordered replay of :591-823
+            if (!(nde < n_frame_errors && experiment <= n_experiments)) { stop = true; break; }
+            ++experiment; ++used;
+            const int iter = iters[(size_t)f];
+            sum_abs_iters += iter < 0 ? -iter : iter;
+            const double *d = decword.data() + (size_t)f * n;
+            int curr_nse = 0, curr_nse_info = 0;                                                 // :735-742
+            for (int i = 0; i < n; ++i)
+                if (d[i] != 0.0) { ++curr_nse; if (i >= r) ++curr_nse_info; }
+            if (curr_nse > 0) {                                                                  // :805-823
+                nse += curr_nse_info; ++nde;
+                if (iter >= 0) ++nue;
+                if (show_process)
+                    printf("SNR=%5.3lf,step=%4d,s_ers=%d,f_ers=%d,u_ers=%d,BER=%5.3le,FER=%5.3le\n", snr, (int)experiment,
+                           (int)nse, (int)nde, (int)nue, (double)nse / experiment / (n - r), (double)nde / experiment);
+                if (nde >= 10 && (double)nde / experiment > 2.5 * reference_frame_error) { stop = true; break; }
+            }
+        }
+        if (used < B) {  // stopped inside the batch: leave the generator where the frame-by-frame loop would
+            Env::generator() = snapshot;
+            for (long long i = 0, cnt = used * n; i < cnt; ++i) (void)Env::gaussian();
+        }
+        if (batch < max_batch) batch *= 4;
+    }
+    ldpc_hip_close(ctx);                                                                         // :831
+    if (counters_out) { counters_out->nse = nse; counters_out->nde = nde; counters_out->nue = nue; counters_out->experiment = experiment; counters_out->sum_abs_iters = sum_abs_iters; }
+    return std::make_pair((double)nse / experiment / (n - r), (double)nde / experiment);         // :840
+}
+
+// Standalone entry point with upstream's argument list (bp_simulation.h:9-27); coef_matrix / ncols2convert only
+// matter for q_mod > 2 (not built) and are accepted and ignored.
+std::pair<double, double> bp_simulation(int q_mod, Matrix const &code_generating_matrix, Matrix &coef_matrix,
+                                        int ncols2convert, int tailbite_length, int max_iterations, int n_frame_errors,
+                                        int n_experiments, double snr, double reference_frame_error, int decoder_type,
+                                        int modulation_type, int permutation_type, int permutation_block,
+                                        int permutation_inter, int punctured_blocks, int show_process);
+
+}  // namespace ldpc
+
+#endif

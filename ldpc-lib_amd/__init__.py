@@ -11,7 +11,7 @@ There is deliberately no CPU fallback: importing works anywhere, but every compu
 """
 from .binding import (DEC_IMS, DEC_LMS, DEC_MS, DEC_SP, LdpcHip, LdpcHipError, build_library, library_path,  # noqa: F401
                       load_library)
-from .host import bp_simulation, relift_base_matrix  # noqa: F401
+from .host import GpuFrameSource, bp_simulation, relift_base_matrix, replay_stopping_rule  # noqa: F401
 
 __all__ = ["LdpcHip", "LdpcHipError", "DEC_SP", "DEC_MS", "DEC_IMS", "DEC_LMS", "build_library", "library_path",
            "load_library", "bp_simulation", "relift_base_matrix"]

@@ -63,29 +63,66 @@ def replay_stopping_rule(frame_info, iters, state, n_frame_errors, n_experiments
     return False
 
 
+class GpuFrameSource:
+    """frames(first_frame, B) -> (frame_info[B], iters[B]) int32 tensors: device noise -> decode -> per-frame accounting
+    for the global frames [first_frame, first_frame + B).  One instance == one opened code on one GPU."""
+
+    def __init__(self, H, tailbite_length, decoder_type, max_iterations, snr, modulation_type, punctured_blocks, seed,
+                 device, alpha):
+        self.dec = LdpcHip(decoder_type, np.asarray(H), tailbite_length, device)
+        self.n, self.r = self.dec.N, self.dec.R
+        self.args = (snr, seed, modulation_type, punctured_blocks, max_iterations, alpha)
+
+    def frames(self, first_frame, B):
+        snr, seed, mod, punct, maxit, alpha = self.args
+        llr = self.dec.awgn_llr(snr, seed, first_frame, B, modulation=mod, punctured_blocks=punct)
+        hard, iters, _ = self.dec.decode(llr, maxit, alpha=alpha)
+        _, info = self.dec.count_errors(hard, iters, want_frame_info=True)
+        return info, iters
+
+    def close(self):
+        self.dec.close()
+
+
 def bp_simulation(H, tailbite_length, max_iterations, n_frame_errors, n_experiments, snr, reference_frame_error,
                   decoder_type=DEC_MS, modulation_type=MODULATION_SKIP, punctured_blocks=0, seed=1, device=0,
-                  batch=16384, first_frame=0, frame_stride=1, alpha=0.8, return_state=False):
-    """Returns (BER, FER) = (nse/experiment/(n-r), nde/experiment) like bp_simulation.cpp:840."""
+                  batch=16384, alpha=0.8, return_state=False, source=None, group=None):
+    """Returns (BER, FER) = (nse/experiment/(n-r), nde/experiment) like bp_simulation.cpp:840.
+
+    Multi-GPU (torch.distributed initialised, one process per GPU): every round covers world*batch consecutive global
+    frames, rank r decodes the r-th slice, the 8-byte per-frame records are all-gathered (no other collective), and
+    every rank replays the sequential stopping rule over the round in global frame order -- so all ranks take the same
+    decisions and the result equals the single-GPU (and the frame-by-frame) result for the same seed.
+    `source` (tests): any object with frames(first, B) -> (info, iters) tensors, n, r, close()."""
     import torch
-    H = np.asarray(H)
-    with LdpcHip(decoder_type, H, tailbite_length, device) as dec:
-        n, r = dec.N, dec.R
-        state = {"nse": 0, "nde": 0, "nue": 0, "experiment": 0, "sum_abs_iters": 0}
-        base = first_frame
-        stop = False
+    import torch.distributed as dist
+    world, rank = 1, 0
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    src = source if source is not None else GpuFrameSource(H, tailbite_length, decoder_type, max_iterations, snr,
+                                                           modulation_type, punctured_blocks, seed, device, alpha)
+    n, r = src.n, src.r
+    state = {"nse": 0, "nde": 0, "nue": 0, "experiment": 0, "sum_abs_iters": 0}
+    base, stop = 0, False
+    try:
         while not stop:
-            B = int(min(batch, max(1, n_experiments + 1 - state["experiment"])))
-            llr = dec.awgn_llr(snr, seed, base, B, modulation=modulation_type, punctured_blocks=punctured_blocks)
-            hard, iters, _ = dec.decode(llr, max_iterations, alpha=alpha)
-            _, info = dec.count_errors(hard, iters, want_frame_info=True)
-            torch.cuda.synchronize(device)
-            info_h, iters_h = info.cpu().numpy(), iters.cpu().numpy()
+            room = max(1, n_experiments + 1 - state["experiment"])
+            B = int(min(batch, -(-room // world)))           # frames per rank this round
+            info, iters = src.frames(base + rank * B, B)
+            rec = torch.stack([info.to(torch.int32), iters.to(torch.int32)])  # [2, B]
+            if world > 1:
+                gathered = [torch.empty_like(rec) for _ in range(world)]
+                dist.all_gather(gathered, rec, group=group)
+                rec = torch.cat(gathered, dim=1)             # global frame order: rank-major slices are consecutive
+            rec_h = rec.cpu().numpy()
             before = state["experiment"]
-            stop = replay_stopping_rule(info_h, iters_h, state, n_frame_errors, n_experiments, reference_frame_error)
+            stop = replay_stopping_rule(rec_h[0], rec_h[1], state, n_frame_errors, n_experiments, reference_frame_error)
             used = state["experiment"] - before
-            state["sum_abs_iters"] += int(np.abs(iters_h[:used]).sum())
-            base += B
+            state["sum_abs_iters"] += int(np.abs(rec_h[1][:used]).sum())
+            base += world * B
+    finally:
+        if source is None:
+            src.close()
     ber = state["nse"] / state["experiment"] / (n - r)
     fer = state["nde"] / state["experiment"]
     return (ber, fer, state) if return_state else (ber, fer)

@@ -288,3 +288,86 @@ def test_every_min_sum_kernel_tier_is_bit_exact(L, torch, monkeypatch, variant, 
 def test_flagship_code_uses_the_ahead_of_time_instance(L):
     with L.LdpcHip(MS_DEC, relift(load_base_matrix(), 64), 64) as dec:
         assert "ahead of time" in dec.kernel_name
+
+
+# ---- the C++ source-compatible layer (include/ldpc/*.h, csrc/compat) -------------------------------------------------
+def _compat_lib(L):
+    import ctypes as C
+    import subprocess
+    L.load_library()  # torch + libldpc_hip.so first: one HIP runtime per process
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "ldpc-lib_amd", "csrc", "compat")])
+    lib = C.CDLL(os.path.join(root, "ldpc-lib_amd", "libldpc_compat.so"))
+    lib.ldpc_bp_simulation_exact.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                             C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p, C.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("dec_id,M,snr,maxit,n_fe,n_exp,ref,mod,punct,seed", [
+    (MS_DEC, 64, 2.0, 50, 10**9, 700, 1.0, 0, 0, 1),        # runs the whole budget: 701 frames (bp_simulation.cpp:591 `<=`)
+    (MS_DEC, 64, 1.2, 50, 10**9, 5000, 0.02, 0, 0, 1),      # stops early on the FER rule (:820): generator roll-back
+    (MS_DEC, 64, 1.4, 50, 7, 5000, 1.0, 0, 0, 3),           # stops on n_frame_errors
+    (LMS_DEC, 126, 1.7, 50, 10**9, 150, 1.0, 0, 0, 1),
+    (MS_DEC, 1, 4.0, 20, 10**9, 2000, 1.0, 0, 0, 1),        # BASELINE config #1 (32,16): FER 0.056 in BASELINE.md
+    (MS_DEC, 64, 2.5, 50, 10**9, 300, 1.0, 1, 0, 5),        # QAM4 formula (:607-612)
+    (MS_DEC, 64, 3.0, 50, 10**9, 200, 1.0, 0, 2, 5),        # two punctured blocks (:697-710)
+])
+def test_exact_replay_harness_equals_the_sequential_harness(L, dec_id, M, snr, maxit, n_fe, n_exp, ref, mod, punct, seed):
+    """C++ bp_simulation on the GPU (batched, host mt19937 noise in upstream's draw order) == the sequential CPU
+    restatement of upstream's frame loop: same counters, same BER/FER doubles, same generator state afterwards."""
+    import ctypes as C
+    from ldpc_testlib import SimResult, c_int_p, oracle_lib
+    lib = _compat_lib(L)
+    H = np.ascontiguousarray(relift(load_base_matrix(), M), dtype=np.int32)
+    out = (C.c_double * 7)()
+    nxt = C.c_uint()
+    rc = lib.ldpc_bp_simulation_exact(16, 32, H.ctypes.data, M, maxit, n_fe, n_exp, snr, ref, dec_id, mod, punct, seed, 0,
+                                      C.addressof(out), C.addressof(nxt))
+    assert rc == 0
+    res = SimResult()
+    assert oracle_lib().orc_bp_simulation(16, 32, H.ctypes.data_as(c_int_p), M, maxit, n_fe, n_exp, snr, ref, dec_id, mod, punct,
+                                          seed, C.byref(res), None) == 0
+    assert (out[2], out[3], out[4], out[5], out[6]) == (res.nse, res.nde, res.nue, res.experiment, res.sum_abs_iter)
+    assert out[0] == res.ber and out[1] == res.fer
+    assert nxt.value == res.rng_next
+    if (dec_id, M, n_exp, seed) == (MS_DEC, 1, 2000, 1):
+        assert res.nde == 112 and res.experiment == 2001   # the FER 0.056 the survey measured with the compiled upstream binary
+
+
+@pytest.mark.parametrize("name", ["ms_m64_1p2", "lms_m64_0p8", "sp_m64_2p0", "ms_m126_1p7", "ms_m1_4p0"])
+def test_decoders_h_call_surface(L, tmp_path, name):
+    """decod_open / hd fill / decod_init / <decoder>(st, st->y, st->decword, ...) / decod_close from a C++ program built
+    against include/ldpc/decoders.h, on the reference's golden vectors."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _compat_lib(L)
+    exe = str(tmp_path / "compat_driver")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "compat_driver.cpp"), "-o", exe,
+                           "-L", os.path.join(root, "ldpc-lib_amd"), "-lldpc_compat", "-lldpc_hip",
+                           "-Wl,-rpath," + os.path.join(root, "ldpc-lib_amd")])
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    H, M, dec_id, maxiter = g["H"], int(g["M"]), int(g["dec_id"]), int(g["maxiter"])
+    for decision, nfr in ((0, g["llr"].shape[0]), (1, g["soft"].shape[0])):
+        llr = g["llr"][:nfr]
+        with open(tmp_path / "in.bin", "wb") as f:
+            f.write(np.array([dec_id, H.shape[0], H.shape[1], M, nfr, maxiter, decision], dtype=np.int32).tobytes())
+            f.write(np.ascontiguousarray(H, dtype=np.int16).tobytes())
+            f.write(np.ascontiguousarray(llr, dtype=np.float64).tobytes())
+        subprocess.check_call([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
+        raw = open(tmp_path / "out.bin", "rb").read()
+        N = H.shape[1] * M
+        iters = np.frombuffer(raw[:4 * nfr], dtype=np.int32)
+        dec = np.frombuffer(raw[4 * nfr:4 * nfr + 8 * nfr * N], dtype=np.float64).reshape(nfr, N)
+        after = np.frombuffer(raw[4 * nfr + 8 * nfr * N:], dtype=np.float64).reshape(nfr, N)
+        assert np.array_equal(iters, g["iters"][:nfr])
+        if decision == 0:
+            assert np.array_equal(pack_bits(dec), g["hard"][:nfr])
+        elif dec_id == SP_DEC:
+            np.testing.assert_allclose(dec, g["soft"], rtol=SP_RTOL)
+        else:
+            assert np.array_equal(dec, g["soft"])
+        if dec_id != SP_DEC:
+            assert np.array_equal(after, llr)          # MS/LMS leave y intact (SURVEY 8b ownership)
+        else:
+            assert not np.array_equal(after, llr)      # SP clobbers its input like upstream (decoders.cpp:1950)
