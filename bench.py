@@ -177,6 +177,17 @@ def main():
     kern_s = kms / 1e3
     achieved = (sum_iters_rank * bytes_iter) / kern_s / 1e9 if kern_s > 0 else None
 
+    # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/prof_pmc.sh):
+    # bench.py cannot collect hardware counters itself, so the figure is reported with its provenance, and only when it
+    # was measured for the kernel and launch shape that just ran.
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if tj["kernel"].split("(")[0] in dec.kernel_name and B == FRAMES_PER_GPU:
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_traffic.json: " + tj["source"]
+    except Exception:
+        pass
+
     out = {
         "metric": "decoded frames/sec, (2048,1024) QC-LDPC, 50 iters min-sum", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
@@ -190,12 +201,14 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
-            "kernel": "ldpc::ms_flood_kernel<16,32,false>", "kernel_ms_avg": kms / max(klaunch, 1), "launches": klaunch,
+            "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic, "traffic_unit": "bytes per launch",
+            "traffic_source": traffic_src,
+            "kernel": dec.kernel_name, "kernel_ms_avg": kms / max(klaunch, 1), "launches": klaunch,
             "algorithmic_bytes_per_frame_iter": bytes_iter,
+            "algorithmic_bytes_per_launch": sum_iters_rank * bytes_iter / max(klaunch, 1),
             "note": "effective message-state bandwidth (SURVEY 8d); the state is VGPR/LDS resident, compulsory HBM bytes "
                     f"per frame = {8 * N} (fp64 LLR in) + {N // 8 + 4} (packed bits + iters out); the kernel is bound by "
-                    "fp64 VALU issue + LDS, not HBM",
+                    "VALU issue (fp64 + half-rate VOP3/compare/select) with LDS ~48% busy, not by HBM (DESIGN.md 4.2)",
         },
     }
 
