@@ -54,6 +54,28 @@ __device__ __forceinline__ double signed_mag(double mag, u32 sign_src) {
 
 constexpr double kMaxVal = 32767.0;  // decoders.cpp:4299-4301
 
+// Lane masks live in SGPR pairs and selects use the VOP3 form.  Measured on gfx950 (tools/ubench_valu3.hip): the
+// VOP2 form `v_cndmask_b32_e32 ..., vcc` exposes ~20 cycles of latency per use at 2 waves per SIMD, the VOP3 form
+// with an SGPR-pair mask issues at the normal half rate (~4.5 cycles).  hipcc shrinks selects to the VOP2 form
+// whenever the mask sits in VCC, hence the explicit instruction.
+typedef unsigned long long mask64;
+__device__ __forceinline__ mask64 lanes_eq(u32 a, u32 b) { return __builtin_amdgcn_uicmp(a, b, 32 /*ICMP_EQ*/); }
+__device__ __forceinline__ mask64 lanes_lt(double a, double b) { return __builtin_amdgcn_fcmp(a, b, 4 /*FCMP_OLT*/); }
+__device__ __forceinline__ u32 sel32(u32 if0, u32 if1, mask64 m) {
+    u32 d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(if0), "v"(if1), "s"(m));
+    return d;
+}
+// x + x as an explicit full-rate VOP2 add (the compiler would turn a chain of these back into half-rate shifts)
+__device__ __forceinline__ u32 twice(u32 x) {
+    u32 d;
+    asm("v_add_u32 %0, %1, %1" : "=v"(d) : "v"(x));
+    return d;
+}
+__device__ __forceinline__ double sel64(double if0, double if1, mask64 m) {
+    return mk(sel32(hi32(if0), hi32(if1), m), sel32(lo32(if0), lo32(if1), m));
+}
+
 template <class C>
 __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
     constexpr int RH = C::RH, NH = C::NH, N = C::NH * 64;
@@ -88,11 +110,11 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
         // re-read every iteration (16 KiB per frame: L2 / Infinity-Cache hits after the first pass) right here, so the
         // loads fly under STATE1's ALU work, and the registers are free again during STATE3 where pressure peaks.
         double y[NH];
-        const double *yp = yrow;
-        asm volatile("" : "+v"(yp));  // opaque per iteration: the loads must not be hoisted out of the loop again
+        int yo = 0;
+        asm volatile("" : "+v"(yo));  // opaque per iteration: the loads must not be hoisted out of the loop again
         static_for<0, NH>([&](auto K) {
             constexpr int k = decltype(K)::value;
-            y[k] = yp[k * 64];
+            y[k] = yrow[yo + k * 64];
         });
         // ---------------- STATE1 (:4633-4667): acc[v] = sum of c2v, ascending block row
         static_for<0, RH>([&](auto J) {
@@ -103,13 +125,15 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
             // and its own (otherwise instruction selection emits all 112 c2v computations first and spills them).
             asm volatile("" : "+v"(mt), "+v"(nb));
             const u32 pos = mt >> 16;
-            const u32 W = (mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u));  // bit s = sign of the c2v on slot s
+            // sign of the c2v on slot s = (own v2c sign) xor (row sign); slot s sits on bit RW-1-s of the row word.
+            // Wt carries slot 0 on bit 31; every further slot is one full-rate add (Wt += Wt) instead of a shift.
+            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - C::RW[j]);
             static_for<0, C::RW[j]>([&](auto S) {
                 constexpr int s = decltype(S)::value;
                 constexpr int k = C::COL[j][s];
-                constexpr int bit = C::RW[j] - 1 - s;
-                const double aa = (pos == (u32)s) ? m2[j] : m1[j];
-                const double cv = signed_mag(aa, W << (31 - bit));
+                const double aa = sel64(m1[j], m2[j], lanes_eq(pos, (u32)s));
+                const double cv = signed_mag(aa, Wt);
+                Wt = twice(Wt);
                 double *p = reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + k * 512);
                 if constexpr (C::FIRST[j][s]) *p = cv;
                 else __hip_atomic_fetch_add(p, cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -134,7 +158,7 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
             // whole iteration to reuse them here (SGPR + VGPR spills to scratch); recomputing costs 3 ops per edge.
             asm volatile("" : "+v"(mt));
             const u32 pos = mt >> 16;
-            const u32 W = (mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u));
+            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - RW);
             double a1 = m1[j] * alpha, a2 = m2[j] * alpha;
             asm volatile("" : "+v"(a1), "+v"(a2));  // two products per ROW, not one per edge
             double nm1 = kMaxVal, nm2 = kMaxVal;    // start value == the MAX_VAL clamp of :4730
@@ -149,14 +173,15 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
             static_for<0, RW>([&](auto S) {
                 constexpr int s = decltype(S)::value;
                 sy ^= hi32(r[s]);
-                const double aa = (pos == (u32)s) ? a2 : a1;
-                const double x = signed_mag(aa, W << (31 - (RW - 1 - s)));
+                const double aa = sel64(a1, a2, lanes_eq(pos, (u32)s));
+                const double x = signed_mag(aa, Wt);
+                Wt = twice(Wt);
                 const double tt = r[s] - x;              // v2c
                 nS = __builtin_amdgcn_alignbit(nS, hi32(tt), 31);  // (nS << 1) | sign(tt): slot s lands on bit RW-1-s
                 const double v = fabs(tt);
-                const bool c1 = v < nm1;                 // strict: the first minimum keeps the position
+                const mask64 c1 = lanes_lt(v, nm1);      // strict: the first minimum keeps the position
                 nm2 = fmin(fmax(v, nm1), nm2);           // = c1 ? nm1 : min(v, nm2)
-                npos = c1 ? (u32)s : npos;
+                npos = sel32(npos, (u32)s, c1);
                 nm1 = fmin(v, nm1);
             });
             failw |= sy;
