@@ -53,6 +53,24 @@ __global__ void __launch_bounds__(64, 2) ms_spec_appendix_c_m64_kernel(const ldp
     ldpc_spec::ms_m64_body<ldpc_spec::CodeAppendixCM64>(a);
 }
 
+__global__ void __launch_bounds__(64, 2) lms_spec_appendix_c_m64_kernel(const ldpc_spec::SpecArgs a) {
+    ldpc_spec::lms_body<ldpc_spec::CodeAppendixCM64>(a);
+}
+__global__ void __launch_bounds__(512, 2) lms_spec_appendix_c_m512_kernel(const ldpc_spec::SpecArgs a) {
+    ldpc_spec::lms_body<ldpc_spec::CodeAppendixCM512>(a);
+}
+
+template <class FC>
+static bool same_code(int rh, int nh, int M, const std::vector<int32_t> &row_start, const std::vector<uint32_t> &edges) {
+    bool same = rh == FC::RH && nh == FC::NH && M == FC::M;
+    for (int j = 0; same && j < rh; ++j) {
+        same = (row_start[j + 1] - row_start[j]) == FC::RW[j];
+        for (int e = row_start[j]; same && e < row_start[j + 1]; ++e)
+            same = (int)(edges[e] >> 16) == FC::COL[j][e - row_start[j]] && (int)(edges[e] & 0xffffu) == FC::SH[j][e - row_start[j]];
+    }
+    return same;
+}
+
 struct ldpc_hip_ctx {
     int decoder_id = 0, device = 0;
     int rh = 0, nh = 0, M = 0, N = 0, R = 0, ne = 0, hard_words = 0;
@@ -65,6 +83,7 @@ struct ldpc_hip_ctx {
     int fast_variant = 2;      // LDPC_HIP_MS_VARIANT: 2 = code-specialised (AOT/JIT) [default], 0 = table kernel with LDS
                                // fp64 atomics, 1 = table kernel read-add-write, -1 = generic kernel
     bool spec_aot = false;     // the opened matrix is the shipped example code: use the ahead-of-time instance
+    int spec_threads = 64;     // workgroup size of the code-specialised kernel (one frame per workgroup)
     const ldpc_jit::Kernel *jit = nullptr;  // code-specialised instance compiled at open() for any other matrix
     std::string kernel_name;   // which decode kernel this context launches (ldpc_hip_kernel_name)
     ldpc::FastTab fast_tab;
@@ -219,14 +238,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
         }
         if (m64 && c->max_rw <= 16 && c->fast_variant == 2) {
             // code-specialised kernel: ahead-of-time instance for the shipped example code, hiprtc for anything else
-            using FC = ldpc_spec::CodeAppendixCM64;
-            bool same = rh == FC::RH && nh == FC::NH;
-            for (int j = 0; same && j < rh; ++j) {
-                same = (row_start[j + 1] - row_start[j]) == FC::RW[j];
-                for (int e = row_start[j]; same && e < row_start[j + 1]; ++e)
-                    same = (int)(edges[e] >> 16) == FC::COL[j][e - row_start[j]] &&
-                           (int)(edges[e] & 0xffffu) == FC::SH[j][e - row_start[j]];
-            }
+            const bool same = same_code<ldpc_spec::CodeAppendixCM64>(rh, nh, M, row_start, edges);
             const char *jenv = getenv("LDPC_HIP_JIT");
             if (same) {
                 c->spec_aot = true;
@@ -238,7 +250,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
                     for (int e = row_start[j]; e < row_start[j + 1]; ++e)
                         rows[j].emplace_back((int)(edges[e] >> 16), (int)(edges[e] & 0xffffu));
                 std::string jerr;
-                c->jit = ldpc_jit::get_ms_m64(device, rows, nh, jerr);
+                c->jit = ldpc_jit::get(device, "ms_m64_body", rows, nh, M, jerr);
                 if (c->jit) {
                     c->kernel_name = "ms_spec_jit (hiprtc)";
                     c->lds_bytes = sizeof(double) * (size_t)c->N;
@@ -247,6 +259,27 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
                             c->kernel_name.c_str());
                 }
             }
+        }
+        if (decoder_id == LDPC_HIP_LMS_DEC && M >= 48 && all_cols_used && c->fast_variant == 2 &&
+            sizeof(double) * (size_t)c->N + 16 <= 160 * 1024) {
+            // code-specialised layered min-sum: one frame per workgroup of ceil(M/64) waves
+            const char *jenv = getenv("LDPC_HIP_JIT");
+            c->spec_threads = ((M + 63) / 64) * 64;
+            if (same_code<ldpc_spec::CodeAppendixCM64>(rh, nh, M, row_start, edges) ||
+                same_code<ldpc_spec::CodeAppendixCM512>(rh, nh, M, row_start, edges)) {
+                c->spec_aot = true;
+                c->kernel_name = M == 64 ? "lms_spec_appendix_c_m64_kernel (ahead of time)" : "lms_spec_appendix_c_m512_kernel (ahead of time)";
+            } else if (!jenv || atoi(jenv) != 0) {
+                std::vector<std::vector<std::pair<int, int>>> rows(rh);
+                for (int j = 0; j < rh; ++j)
+                    for (int e = row_start[j]; e < row_start[j + 1]; ++e)
+                        rows[j].emplace_back((int)(edges[e] >> 16), (int)(edges[e] & 0xffffu));
+                std::string jerr;
+                c->jit = ldpc_jit::get(device, "lms_body", rows, nh, M, jerr);
+                if (c->jit) c->kernel_name = "lms_spec_jit (hiprtc)";
+                else fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", jerr.c_str(), c->kernel_name.c_str());
+            }
+            if (c->spec_aot || c->jit) c->lds_bytes = sizeof(double) * (size_t)c->N + 16;
         }
     } else {
         c->multiwave = true;
@@ -333,10 +366,10 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
             ldpc_spec::SpecArgs sa{};
             sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
             if (c->spec_aot) {
-                hipLaunchKernelGGL(ms_spec_appendix_c_m64_kernel, grid, block, c->lds_bytes, stream, sa);
+                hipLaunchKernelGGL(ms_spec_appendix_c_m64_kernel, dim3((unsigned)B), dim3(64), c->lds_bytes, stream, sa);
             } else {
                 void *kargs[] = {&sa};
-                HIP_TRY(hipModuleLaunchKernel(c->jit->fn, grid.x, 1, 1, 64, 1, 1, (unsigned)c->lds_bytes, stream, kargs, nullptr));
+                HIP_TRY(hipModuleLaunchKernel(c->jit->fn, (unsigned)B, 1, 1, 64, 1, 1, (unsigned)c->lds_bytes, stream, kargs, nullptr));
             }
         } else if (c->fast_m64) {
             if (c->fast_variant == 1) hipLaunchKernelGGL(ldpc::ms_flood_m64_kernel<false>, grid, block, c->lds_bytes, stream, a, c->fast_tab);
@@ -352,7 +385,21 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
         }
         break;
     case LDPC_HIP_LMS_DEC:
-        if (c->multiwave) {
+        if (c->spec_aot || c->jit) {
+            ldpc_spec::SpecArgs sa{};
+            sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
+            if (B > 0x7fffffffLL) return fail(LDPC_HIP_EINVAL, "batch too large");
+            if (c->spec_aot && c->M == 64) {
+                hipLaunchKernelGGL(lms_spec_appendix_c_m64_kernel, dim3((unsigned)B), dim3(64), c->lds_bytes, stream, sa);
+            } else if (c->spec_aot) {
+                if (int rc = set_lds_limit(lms_spec_appendix_c_m512_kernel, c->lds_bytes)) return rc;
+                hipLaunchKernelGGL(lms_spec_appendix_c_m512_kernel, dim3((unsigned)B), dim3(512), c->lds_bytes, stream, sa);
+            } else {
+                void *kargs[] = {&sa};
+                HIP_TRY(hipModuleLaunchKernel(c->jit->fn, (unsigned)B, 1, 1, (unsigned)c->spec_threads, 1, 1, (unsigned)c->lds_bytes, stream,
+                                              kargs, nullptr));
+            }
+        } else if (c->multiwave) {
             auto k = ldpc::lms_layered_kernel<kRHM, kRWM, true>;
             if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
             hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);

@@ -64,7 +64,7 @@ inline Rtc *rtc(std::string &err) {
 }
 
 // `struct Code` for ms_m64_body<>: rows[j] = list of (block column, shift) in ascending column order
-inline std::string code_struct(const std::vector<std::vector<std::pair<int, int>>> &rows, int nh) {
+inline std::string code_struct(const std::vector<std::vector<std::pair<int, int>>> &rows, int nh, int M) {
     const int rh = (int)rows.size();
     size_t wmax = 1;
     for (auto &r : rows) wmax = r.size() > wmax ? r.size() : wmax;
@@ -84,7 +84,7 @@ inline std::string code_struct(const std::vector<std::vector<std::pair<int, int>
     }
     std::ostringstream o;
     o << "struct Code {\n"
-      << "    static constexpr int RH = " << rh << ", NH = " << nh << ", WMAX = " << wmax << ";\n"
+      << "    static constexpr int RH = " << rh << ", NH = " << nh << ", M = " << M << ", WMAX = " << wmax << ";\n"
       << "    static constexpr int RW[" << rh << "] = {" << rw.str() << "};\n"
       << "    static constexpr int COL[" << rh << "][" << wmax << "] = {" << col.str() << "};\n"
       << "    static constexpr int SH[" << rh << "][" << wmax << "] = {" << sh.str() << "};\n"
@@ -101,13 +101,15 @@ inline std::string this_library_dir() {
     return k == std::string::npos ? "." : p.substr(0, k);
 }
 
-// Returns the cached or freshly compiled kernel for (device, rows); nullptr + err on failure.
-inline const Kernel *get_ms_m64(int device, const std::vector<std::vector<std::pair<int, int>>> &rows, int nh,
-                                std::string &err) {
+// Returns the cached or freshly compiled kernel for (device, decoder body, rows, M); nullptr + err on failure.
+// body: "ms_m64_body" (needs M == 64, 64 threads per frame) or "lms_body" (ceil(M/64)*64 threads per frame).
+inline const Kernel *get(int device, const char *body, const std::vector<std::vector<std::pair<int, int>>> &rows, int nh,
+                         int M, std::string &err) {
     static std::mutex mu;
     static std::map<std::string, Kernel> cache;
-    const std::string code = code_struct(rows, nh);
-    const std::string key = std::to_string(device) + "|" + code;
+    const std::string code = code_struct(rows, nh, M);
+    const int threads = ((M + 63) / 64) * 64;
+    const std::string key = std::to_string(device) + "|" + body + "|" + code;
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return &it->second;
@@ -121,8 +123,8 @@ inline const Kernel *get_ms_m64(int device, const std::vector<std::vector<std::p
     hs << hf.rdbuf();
     const std::string hdr = hs.str();
     const std::string src = "#include \"ldpc_ms_spec.hpp\"\nnamespace {\n" + code +
-                            "}\nextern \"C\" __global__ void __launch_bounds__(64, 2) ms_spec_jit(const ldpc_spec::SpecArgs a) {\n"
-                            "    ldpc_spec::ms_m64_body<Code>(a);\n}\n";
+                            "}\nextern \"C\" __global__ void __launch_bounds__(" + std::to_string(threads) + ", 2) spec_jit(const ldpc_spec::SpecArgs a) {\n"
+                            "    ldpc_spec::" + body + "<Code>(a);\n}\n";
     hiprtcProgram prog = nullptr;
     const char *hdr_src[] = {hdr.c_str()};
     const char *hdr_name[] = {"ldpc_ms_spec.hpp"};
@@ -146,7 +148,7 @@ inline const Kernel *get_ms_m64(int device, const std::vector<std::vector<std::p
     r->DestroyProgram(&prog);
     Kernel k;
     if (hipSetDevice(device) != hipSuccess || hipModuleLoadData(&k.mod, bin.data()) != hipSuccess ||
-        hipModuleGetFunction(&k.fn, k.mod, "ms_spec_jit") != hipSuccess) {
+        hipModuleGetFunction(&k.fn, k.mod, "spec_jit") != hipSuccess) {
         err = std::string("loading the JIT code object failed: ") + hipGetErrorString(hipGetLastError());
         return nullptr;
     }

@@ -1,4 +1,5 @@
-// ldpc_ms_spec.hpp -- code-specialised flooding min-sum for lifting M = 64 (one frame == one wavefront).
+// ldpc_ms_spec.hpp -- code-specialised decoders: flooding min-sum for lifting M = 64 (one frame == one wavefront)
+// and layered min-sum for any M <= 512 (one frame == one workgroup).
 //
 // The Tanner graph is a compile-time constant of this kernel: a `Code` type carries the base matrix (block row
 // weights, block column and shift of every circulant) as constexpr tables, so the instruction stream contains
@@ -78,6 +79,7 @@ __device__ __forceinline__ double sel64(double if0, double if1, mask64 m) {
 
 template <class C>
 __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
+    static_assert(C::M == 64, "ms_m64_body: one frame per wavefront needs M == 64");
     constexpr int RH = C::RH, NH = C::NH, N = C::NH * 64;
     extern __shared__ double lds[];  // [N] soft / acc (fp64)
     char *const ldsb = reinterpret_cast<char *>(lds);
@@ -207,6 +209,153 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
         static_for<0, NH>([&](auto K) {
             constexpr int k = decltype(K)::value;
             a.soft_out[fr * N + k * 64 + lane] = *reinterpret_cast<const double *>(ldsb + n8 + k * 512);
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Layered offset min-sum (upstream lmin_sum_decod_qc_lm, decoders.cpp:5064-5425, active branch :5106-5290 with
+// MY_VERSION; semantics SURVEY Appendix A.3), code-specialised like the flooding kernel above, for any lifting
+// M <= 512: one frame per workgroup of W = ceil(M/64) wavefronts, a-posteriori values in LDS (8 B per variable,
+// 128 KiB at (16384,8192)), check records in VGPRs.  Block rows (layers) are strictly sequential: one workgroup
+// barrier per layer when W > 1; inside a layer every variable is touched by exactly one check, so the two passes
+// of a layer (read v2c / write back) need no synchronisation.  beta = 0.4 (:5163); upstream's alpha/beta arguments
+// are dead.  Bit-identical to the reference (hard bits, iteration counts, soft values).
+// ---------------------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void lms_body(const SpecArgs &a) {
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, W = (M + 63) / 64;
+    constexpr bool POW2 = (M & (M - 1)) == 0;
+    constexpr double beta = 0.4;
+    extern __shared__ double lds[];  // [N] soft, then one flag word
+    char *const ldsb = reinterpret_cast<char *>(lds);
+    int *const flag = reinterpret_cast<int *>(ldsb + (size_t)N * 8);
+    const int n = threadIdx.x;       // check row inside a circulant == variable index inside a block column
+    const bool valid = (M % 64 == 0) || n < M;
+    const u32 n8 = (u32)(valid ? n : 0) * 8u;
+    const long long fr = blockIdx.x;
+
+    // byte offset inside a block column of variable (n + shift) mod M
+    auto rot = [&](u32 base, auto S) -> u32 {
+        constexpr int c = decltype(S)::value;
+        if constexpr (c == 0) return base;
+        else if constexpr (POW2) return (base + 8u * (u32)c) & (u32)(8 * M - 1);
+        else { const u32 t = base + 8u * (u32)c; return t >= (u32)(8 * M) ? t - (u32)(8 * M) : t; }
+    };
+    auto vote = [&](bool fail) -> bool {  // does any check of the frame fail?
+        if constexpr (W == 1) return __ballot(fail) != 0ull;
+        else {
+            if (threadIdx.x == 0) *flag = 0;
+            __syncthreads();
+            if (__ballot(fail) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+            __syncthreads();
+            const bool r = *flag != 0;
+            __syncthreads();
+            return r;
+        }
+    };
+    // check_syndrome (decoders.cpp:793-814) of the current soft values
+    auto syndrome_fail = [&]() -> bool {
+        u32 failw = 0;
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            u32 sy = 0, nb = n8;
+            asm volatile("" : "+v"(nb));
+            static_for<0, C::RW[j]>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                sy ^= *reinterpret_cast<const u32 *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M) + 4);  // high dword
+            });
+            failw |= sy;
+        });
+        return valid && (failw >> 31);
+    };
+
+    if (valid) {
+        static_for<0, NH>([&](auto K) {   // :5088 soft = y
+            constexpr int k = decltype(K)::value;
+            *reinterpret_cast<double *>(ldsb + n8 + k * (8 * M)) = a.llr[fr * N + k * M + n] + 0.0;
+        });
+    }
+    double m1[RH], m2[RH];
+    u32 meta[RH];
+    static_for<0, RH>([&](auto J) { constexpr int j = decltype(J)::value; m1[j] = 0.0; m2[j] = 0.0; meta[j] = 0u; });
+    if constexpr (W > 1) __syncthreads();
+
+    int res = -a.maxiter;                                  // :5424 when the loop runs dry
+    bool fail = vote(syndrome_fail());                     // :5111-5115
+    if (!fail) res = 1;                                    // :5119 at iter 0
+    for (int iter = 0; fail && iter < a.maxiter; ++iter) {
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int RW = C::RW[j];
+            u32 mt = meta[j], nb = n8;
+            asm volatile("" : "+v"(mt), "+v"(nb));         // anchor: keeps this layer's ALU work behind the barrier
+            const u32 pos = mt >> 16;
+            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - RW);
+            double nm1 = kMaxVal, nm2 = kMaxVal;           // :5133-5134 (no clamp of the v2c magnitudes in this decoder)
+            u32 npos = 0, nS = 0;
+            double r[RW], tv[RW];
+            static_for<0, RW>([&](auto S) {                // :5141-5177
+                constexpr int s = decltype(S)::value;
+                r[s] = *reinterpret_cast<const double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M));
+            });
+            static_for<0, RW>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                const double aa = sel64(m1[j], m2[j], lanes_eq(pos, (u32)s));
+                const double pc = signed_mag(aa, Wt);       // previous c2v (no alpha, no beta here)
+                Wt = twice(Wt);
+                const double tt = r[s] - pc;
+                tv[s] = tt;
+                nS = __builtin_amdgcn_alignbit(nS, hi32(tt), 31);   // sign kept even when the magnitude clips to 0 (:5164-5168)
+                double mag = fabs(tt) - beta;
+                mag = mag < 0 ? 0 : mag;
+                const mask64 c1 = lanes_lt(mag, nm1);       // process_check_node :5012-5027
+                nm2 = fmin(fmax(mag, nm1), nm2);
+                npos = sel32(npos, (u32)s, c1);
+                nm1 = fmin(mag, nm1);
+            });
+            u32 Wn = (nS ^ (0u - (__popc(nS) & 1u))) << (32 - RW);
+            static_for<0, RW>([&](auto S) {                // :5182-5206
+                constexpr int s = decltype(S)::value;
+                const double aa = sel64(nm1, nm2, lanes_eq(npos, (u32)s));
+                const double cv = signed_mag(aa, Wn);
+                Wn = twice(Wn);
+                if (valid) *reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M)) = tv[s] + cv;
+            });
+            m1[j] = nm1; m2[j] = nm2; meta[j] = nS | (npos << 16);
+            if constexpr (W > 1) __syncthreads();           // the next layer reads what this one wrote
+            else __builtin_amdgcn_sched_barrier(0);
+        });
+        fail = vote(syndrome_fail());                       // :5281-5284
+        if (!fail) res = iter + 1;                          // :5287
+    }
+
+    if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
+    if (a.hard) {
+        if constexpr (M % 64 == 0) {
+            // this wave's 64 variables of block column k are the packed words 2*(k*W + wave) and +1
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            static_for<0, NH>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                const u64 b = __ballot((*reinterpret_cast<const u32 *>(ldsb + n8 + k * (8 * M) + 4) >> 31) != 0);
+                if (lane == 0) reinterpret_cast<u64 *>(a.hard + fr * (N / 32))[k * W + wave] = b;
+            });
+        } else {
+            constexpr int HW = (N + 31) / 32;
+            for (int w = threadIdx.x; w < HW; w += W * 64) {
+                u32 bits = 0;
+                for (int b = 0; b < 32; ++b) {
+                    const int v = 32 * w + b;
+                    if (v < N) bits |= (*reinterpret_cast<const u32 *>(ldsb + (size_t)v * 8 + 4) >> 31) << b;
+                }
+                a.hard[fr * HW + w] = bits;
+            }
+        }
+    }
+    if (a.soft_out && valid) {
+        static_for<0, NH>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            a.soft_out[fr * N + k * M + n] = *reinterpret_cast<const double *>(ldsb + n8 + k * (8 * M));
         });
     }
 }

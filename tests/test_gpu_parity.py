@@ -371,3 +371,25 @@ def test_decoders_h_call_surface(L, tmp_path, name):
             assert np.array_equal(after, llr)          # MS/LMS leave y intact (SURVEY 8b ownership)
         else:
             assert not np.array_equal(after, llr)      # SP clobbers its input like upstream (decoders.cpp:1950)
+
+
+@pytest.mark.parametrize("M,frames", [(64, 96), (126, 24), (200, 12), (512, 6)])
+def test_layered_min_sum_specialised_instances(L, torch, M, frames):
+    """hiprtc instances of lms_body (power-of-two and other liftings, 1..8 waves per frame) against the oracle."""
+    H = relift(load_base_matrix(), M)
+    H2 = H.copy()
+    H2[H > 0] = (H[H > 0] * 5 + 1) % M          # not the ahead-of-time matrices
+    llr = np.concatenate([awgn_llr(H2, M, s, 60 + i, frames // 2) for i, s in enumerate((1.0, 2.0))])
+    o = Oracle(H2, M)
+    d_ref, it_ref, _ = o.decode(LMS_DEC, llr, 50, 0)
+    s_ref, _, _ = o.decode(LMS_DEC, llr, 50, 1)
+    with L.LdpcHip(LMS_DEC, H2, M) as dec:
+        assert "jit" in dec.kernel_name, dec.kernel_name
+        hard, iters, soft = dec.decode(torch.from_numpy(llr).cuda(), 50, want_soft=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(iters.cpu().numpy(), it_ref)
+        assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
+        assert np.array_equal(soft.cpu().numpy(), s_ref)
+    for Maot in (64, 512):
+        with L.LdpcHip(LMS_DEC, relift(load_base_matrix(), Maot), Maot) as dec:
+            assert "ahead of time" in dec.kernel_name
