@@ -64,6 +64,7 @@ const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *ctx);
  *   MS_DEC : min_sum_decod_qc_lm(st, y, decword, maxiter, decision, alpha)
  *   LMS_DEC: lmin_sum_decod_qc_lm(st, y, decword, maxiter, decision, alpha, beta)   (alpha, beta dead upstream)
  *   SP_DEC : sum_prod_decod_qc_lm(st, soft, decword, maxiter, decision)
+ *   IMS_DEC: imin_sum_decod_qc_lm(st, y, decword, maxiter, decision, alpha, thr, qbits, dbits)  (int16 min-sum)
  * All pointers are DEVICE pointers on ctx's device; the work is enqueued on `stream` (a hipStream_t, NULL =
  * default stream) and is asynchronous.
  *   d_llr   [B][N] float64 in.   NOT modified (upstream SP clobbers its input; the clobbered values are what
@@ -76,6 +77,10 @@ const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *ctx);
  */
 int ldpc_hip_decode_dev(ldpc_hip_ctx *ctx, const double *d_llr, long long B, int maxiter, double alpha,
                         uint32_t *d_hard, int32_t *d_iters, double *d_soft, void *stream);
+
+/* Integer min-sum only: the quantiser arguments of imin_sum_decod_qc_lm (decoders.h:300; defaults MS_THR 1.4,
+ * MS_QBITS 6, MS_DBITS 8 of decoders.h:46-48).  `alpha` of the decode calls gives ialpha = (int)(alpha*16). */
+int ldpc_hip_set_ims_params(ldpc_hip_ctx *ctx, double thr, int qbits, int dbits);
 
 /* Same with HOST pointers, laid out exactly like upstream's per-frame arrays (PCIe-inclusive, synchronous):
  *   llr [B][N] in (for SP it is overwritten like upstream's soft[] when clobber_sp_input != 0),

@@ -79,6 +79,8 @@ struct ldpc_hip_ctx {
     int threads = 64; // workgroup size of the decode kernel
     bool multiwave = false;
     size_t lds_bytes = 0;
+    double ims_thr = 1.4;      // MS_THR, MS_QBITS, MS_DBITS (decoders.h:46-48), see ldpc_hip_set_ims_params
+    int ims_qbits = 6, ims_dbits = 8;
     bool fast_m64 = false;     // flagship path: min-sum, M == 64, table in the kernel-argument segment
     int fast_variant = 2;      // LDPC_HIP_MS_VARIANT: 2 = code-specialised (AOT/JIT) [default], 0 = table kernel with LDS
                                // fp64 atomics, 1 = table kernel read-add-write, -1 = generic kernel
@@ -160,8 +162,8 @@ int ldpc_hip_device_count(void) {
 int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int device, ldpc_hip_ctx **out) {
     if (out) *out = nullptr;
     if (!out || !hd || rh <= 0 || nh <= 0 || M <= 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_open: bad argument");
-    if (decoder_id != LDPC_HIP_MS_DEC && decoder_id != LDPC_HIP_LMS_DEC && decoder_id != LDPC_HIP_SP_DEC)
-        return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_open: decoder id %d is not built (built: SP=1, MS=3, LMS=8)", decoder_id);
+    if (decoder_id != LDPC_HIP_MS_DEC && decoder_id != LDPC_HIP_LMS_DEC && decoder_id != LDPC_HIP_SP_DEC && decoder_id != LDPC_HIP_IMS_DEC)
+        return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_open: decoder id %d is not built (built: SP=1, MS=3, IMS=4, LMS=8)", decoder_id);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(LDPC_HIP_EINVAL, "ldpc_hip_open: device %d of %d", device, ndev);
@@ -204,10 +206,10 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
 
     // what the kernels were instantiated for
     if (M >= 65536 || nh >= 65536) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "M and nh must be < 65536"); }
-    if (decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC) {
+    if (decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || decoder_id == LDPC_HIP_IMS_DEC) {
         if (rh > kRHM) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "rh=%d > %d block rows", rh, kRHM); }
         if (c->max_rw > kRWM) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "row weight %d > %d", c->max_rw, kRWM); }
-        if (decoder_id == LDPC_HIP_MS_DEC && nh > kNHM) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "nh=%d > %d block columns", nh, kNHM); }
+        if ((decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_IMS_DEC) && nh > kNHM) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "nh=%d > %d block columns", nh, kNHM); }
         if (M > 512) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "M=%d > 512", M); }
         c->multiwave = M > 64;
         c->F = c->multiwave ? 1 : 64 / M;
@@ -218,7 +220,8 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
         const char *venv = getenv("LDPC_HIP_MS_VARIANT");
         c->fast_variant = venv ? atoi(venv) : 2;
         c->kernel_name = decoder_id == LDPC_HIP_MS_DEC ? (c->multiwave ? "ms_flood_kernel<multiwave>" : "ms_flood_kernel")
-                                                       : (c->multiwave ? "lms_layered_kernel<multiwave>" : "lms_layered_kernel");
+                       : decoder_id == LDPC_HIP_IMS_DEC ? (c->multiwave ? "ims_flood_kernel<multiwave>" : "ims_flood_kernel")
+                                                        : (c->multiwave ? "lms_layered_kernel<multiwave>" : "lms_layered_kernel");
         const bool m64 = decoder_id == LDPC_HIP_MS_DEC && M == 64 && rh <= ldpc::kFastRows && nh <= ldpc::kFastCols && all_cols_used;
         if (m64 && c->max_rw <= ldpc::kFastSlots && c->fast_variant >= 0) {
             // table-driven M = 64 kernel (always available)
@@ -349,6 +352,7 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
     a.col_start = c->d_col_start; a.col_edges = c->d_col_edges; a.col_slot = c->d_col_slot;
     a.B = B; a.rh = c->rh; a.nh = c->nh; a.M = c->M; a.N = c->N; a.F = c->F;
     a.maxiter = maxiter; a.hard_words = c->hard_words; a.alpha = alpha;
+    a.ims_thr = c->ims_thr; a.ims_qbits = c->ims_qbits; a.ims_dbits = c->ims_dbits;
 
     const long long blocks = (B + c->F - 1) / c->F;
     if (blocks > 0x7fffffffLL) return fail(LDPC_HIP_EINVAL, "batch too large");
@@ -406,6 +410,16 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
         } else {
             auto k = ldpc::lms_layered_kernel<kRHM, kRWM, false>;
             if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
+            hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
+        }
+        break;
+    case LDPC_HIP_IMS_DEC:
+        if (c->multiwave) {
+            auto k = ldpc::ims_flood_kernel<kRHM, kNHM, true>;
+            if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
+            hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
+        } else {
+            auto k = ldpc::ims_flood_kernel<kRHM, kNHM, false>;
             hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
         }
         break;
@@ -567,6 +581,13 @@ int ldpc_hip_simulate(ldpc_hip_ctx *c, double snr_db, int modulation_type, int p
     HIP_TRY(hipMemcpy(h, c->w_counters, sizeof h, hipMemcpyDeviceToHost));
     counters[0] = h[0]; counters[1] = h[1]; counters[2] = h[2]; counters[3] = h[3];
     if (sum_abs_iters) *sum_abs_iters = h[4];
+    return 0;
+}
+
+int ldpc_hip_set_ims_params(ldpc_hip_ctx *c, double thr, int qbits, int dbits) {
+    if (!c || !(thr > 0) || qbits < 2 || qbits > 15 || dbits < 2 || dbits > 15)
+        return fail(LDPC_HIP_EINVAL, "ldpc_hip_set_ims_params: bad argument");
+    c->ims_thr = thr; c->ims_qbits = qbits; c->ims_dbits = dbits;
     return 0;
 }
 

@@ -45,6 +45,8 @@ struct DecArgs {
     long long B;
     int rh, nh, M, N, F, maxiter, hard_words;
     double alpha;
+    double ims_thr;           // integer min-sum quantiser (decoders.h:46-48): threshold, bits of the input, bits of the data path
+    int ims_qbits, ims_dbits;
 };
 
 __device__ __forceinline__ uint32_t hi32(double x) { return (uint32_t)__double2hiint(x); }
@@ -339,6 +341,149 @@ __global__ void __launch_bounds__(MW ? 512 : 64) lms_layered_kernel(const DecArg
         if (!done && !frame_fail) { done = true; res = iter + 1; }          // :5287, returns iter+1
     }
     write_outputs<MW>(a, lds, fr, n, f, live, res, 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Integer min-sum (imin_sum_decod_qc_lm, decoders.cpp:5430-5690; semantics SURVEY Appendix A.4): the flooding
+// schedule of ms_flood_kernel on int16 values.  Input quantiser: coef = sqrt(N / sum y^2) with the sum taken in
+// index order (a parallel reduction would round differently and could move a value across a quantiser boundary),
+// q = floor(min(|y|*coef, thr)*max_quant/thr + 0.5) with the sign of y; c2v magnitudes are scaled (a*ialpha)>>4 in
+// STATE1 and STATE3, STATE1 saturates at +-max_data after every add, STATE2 is sat(iy + acc) (no alpha).  Everything
+// after the quantiser is integer arithmetic, so the GPU result is exact by construction; values never leave
+// [-2*max_data, 2*max_data], so 32-bit lanes reproduce the reference's int16 arithmetic without wrap-around.
+// LDS: one int32 per variable.
+// ---------------------------------------------------------------------------------------------------------
+template <int RHM, int NHM, bool MW>
+__global__ void __launch_bounds__(MW ? 512 : 64) ims_flood_kernel(const DecArgs a) {
+    extern __shared__ double lds_raw[];
+    int *const lds = reinterpret_cast<int *>(lds_raw);  // [N][F] soft / acc
+    const int M = a.M, F = a.F, N = a.N, rh = a.rh, nh = a.nh;
+    int *const sh_flag = lds + (size_t)N * F;
+    const int max_data = (1 << (a.ims_dbits - 1)) - 1;   // :5445
+    const int max_quant = (1 << (a.ims_qbits - 1)) - 1;  // :5446
+    const int ialpha = (int)(a.alpha * (1 << 4));         // :5458 MS_ALPHA_FPP = 4
+    int n, f;
+    const bool valid = lane_map<MW>(F, M, n, f);
+    const unsigned long long per = MW ? 0ull : slot_mask(F);
+    const long long fr = (long long)blockIdx.x * F + f;
+    const bool inb = fr < a.B;
+    const bool live = valid && inb;
+    auto sat = [&](int x) { return x > max_data ? max_data : (x < -max_data ? -max_data : x); };  // limit_val :4308
+
+    // :5472-5500 energy-normalised quantiser.  Every lane of a frame walks the frame's LLRs in index order (same
+    // addresses within the frame: broadcast loads), so all of them hold the identical, sequentially rounded sum.
+    int iy[NHM];
+    {
+        double en = 0;
+        const double *yf = a.llr + (inb ? fr : 0) * (long long)N;
+        for (int i = 0; i < N; ++i) { const double v = yf[i]; en += v * v; }
+        const double coef = sqrt((double)N / en);
+#pragma unroll
+        for (int k = 0; k < NHM; ++k) {
+            iy[k] = 0;
+            if (k < nh && live) {
+                double val = yf[k * M + n];
+                int sign = 0;
+                if (val < 0) { val = -val; sign = 1; }
+                val *= coef;
+                if (val > a.ims_thr) val = a.ims_thr;
+                const int ival = (int)(short)floor(val * max_quant / a.ims_thr + 0.5);
+                iy[k] = sign ? -ival : ival;
+            }
+        }
+    }
+    int m1[RHM], m2[RHM];
+    uint32_t meta[RHM];
+#pragma unroll
+    for (int j = 0; j < RHM; ++j) { m1[j] = 0; m2[j] = 0; meta[j] = 0u; }
+
+    bool done = !inb;
+    int res = -a.maxiter;
+    for (int iter = 0; iter < a.maxiter; ++iter) {
+        const bool wr = !done && valid;
+        if (wr) {
+#pragma unroll
+            for (int k = 0; k < NHM; ++k) if (k < nh) lds[(k * M + n) * F + f] = 0;
+        }
+        if (MW) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RHM; ++j) {   // STATE1 :5540-5576
+            if (j < rh) {
+                const int e0 = a.row_start[j], rw = a.row_start[j + 1] - e0;
+                const uint32_t mt = meta[j];
+                const uint32_t par = __popc(mt & 0xffffu) & 1u;
+                const uint32_t pos = mt >> kRowBits;
+                for (int idx = 0; idx < rw; ++idx) {
+                    const uint32_t d = a.edges[e0 + idx];
+                    const int k = d >> 16, c = d & 0xffffu;
+                    const int addr = (k * M + rot_idx(n, c, M)) * F + f;
+                    int tmp = (pos == (uint32_t)idx) ? m2[j] : m1[j];
+                    tmp = (tmp * ialpha) >> 4;
+                    const int cv = (((mt >> idx) ^ par) & 1u) ? -tmp : tmp;
+                    if (wr) lds[addr] = sat(lds[addr] + cv);
+                }
+                if (MW) __syncthreads();
+            }
+        }
+        if (wr) {                          // STATE2 :5579-5604
+#pragma unroll
+            for (int k = 0; k < NHM; ++k) {
+                if (k < nh) {
+                    const int o = (k * M + n) * F + f;
+                    lds[o] = sat(iy[k] + lds[o]);
+                }
+            }
+        }
+        if (MW) __syncthreads();
+        uint32_t failw = 0;
+#pragma unroll
+        for (int j = 0; j < RHM; ++j) {   // STATE3 :5610-5678
+            if (j < rh) {
+                const int e0 = a.row_start[j], rw = a.row_start[j + 1] - e0;
+                const uint32_t mt = meta[j];
+                const uint32_t par = __popc(mt & 0xffffu) & 1u;
+                const uint32_t pos = mt >> kRowBits;
+                int nm1 = max_data, nm2 = max_data;
+                uint32_t npos = 0, nS = 0, sy = 0;
+                for (int idx = 0; idx < rw; ++idx) {
+                    const uint32_t d = a.edges[e0 + idx];
+                    const int k = d >> 16, c = d & 0xffffu;
+                    const int r = lds[(k * M + rot_idx(n, c, M)) * F + f];
+                    sy ^= (uint32_t)r;
+                    const int aa = (pos == (uint32_t)idx) ? m2[j] : m1[j];
+                    const int val = (aa * ialpha) >> 4;
+                    const int t = (((mt >> idx) ^ par) & 1u) ? -val : val;
+                    const int msg = r - t;
+                    nS |= ((uint32_t)msg >> 31) << idx;
+                    int v = msg < 0 ? -msg : msg;
+                    v = v > max_data ? max_data : v;
+                    if (v < nm1) { npos = idx; nm2 = nm1; nm1 = v; }
+                    else if (v < nm2) nm2 = v;
+                }
+                failw |= sy;
+                if (!done) { m1[j] = nm1; m2[j] = nm2; meta[j] = nS | (npos << kRowBits); }
+            }
+        }
+        const bool fail = valid && (failw >> 31);
+        const bool frame_fail = frame_vote<MW>(fail, F, f, per, sh_flag);
+        if (!done && !frame_fail) { done = true; res = iter + 1; }  // :5684-5689
+        if (MW) { if (done) break; }
+        else if (__all(done)) break;
+    }
+    if (!live) return;
+    if (n == 0 && a.iters) a.iters[fr] = res;
+    if (a.hard) {
+        for (int w = n; w < a.hard_words; w += M) {
+            uint32_t bits = 0;
+            for (int b = 0; b < 32; ++b) {
+                const int v = 32 * w + b;
+                if (v < N) bits |= ((uint32_t)lds[v * F + f] >> 31) << b;
+            }
+            a.hard[fr * a.hard_words + w] = bits;
+        }
+    }
+    if (a.soft_out)
+        for (int k = 0; k < nh; ++k) a.soft_out[fr * N + k * M + n] = (double)lds[(k * M + n) * F + f];
 }
 
 }  // namespace ldpc

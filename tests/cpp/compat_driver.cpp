@@ -37,6 +37,7 @@ int main(int argc, char **argv) {
         switch (dec_id) {                                               // bp_simulation.cpp:716-729
         case SP_DEC: it = sum_prod_decod_qc_lm(st, st->y, st->decword, maxiter, decision); break;
         case MS_DEC: it = min_sum_decod_qc_lm(st, st->y, st->decword, maxiter, decision, MS_ALPHA); break;
+        case IMS_DEC: it = imin_sum_decod_qc_lm(st, st->y, st->decword, maxiter, decision, MS_ALPHA, MS_THR, MS_QBITS, MS_DBITS); break;
         default:     it = lmin_sum_decod_qc_lm(st, st->y, st->decword, maxiter, decision, MS_ALPHA, MS_BETA); break;
         }
         iters[b] = it;

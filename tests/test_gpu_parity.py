@@ -6,13 +6,13 @@ import os
 import numpy as np
 import pytest
 
-from ldpc_testlib import (GOLDEN_DIR, LMS_DEC, MS_DEC, SP_DEC, Oracle, awgn_llr, bpsk_sigma, load_base_matrix, pack_bits,
+from ldpc_testlib import (GOLDEN_DIR, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, Oracle, awgn_llr, bpsk_sigma, load_base_matrix, pack_bits,
                           philox_gauss_pairs, relift, syndrome_np, unpack_bits)
 
 pytestmark = pytest.mark.gpu
 
 DECODER_SETS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                      if os.path.basename(p).split("_")[0] in ("ms", "lms", "sp"))
+                      if os.path.basename(p).split("_")[0] in ("ms", "lms", "sp", "ims"))
 
 # sum-product soft values: exp() is ocml on the device and glibc in the reference (each within 1 ulp of the true
 # value, not identical to each other); every other operation is IEEE-exact and in the reference's order.  The 1-ulp
@@ -64,6 +64,9 @@ def test_golden_vectors_host_api(L, name):
     (MS_DEC, 100, (1.8,), 24, 50),      # 2 waves per frame, 28 idle lanes
     (LMS_DEC, 200, (1.5,), 12, 50),     # 4 waves per frame
     (SP_DEC, 33, (2.0,), 40, 25),
+    (IMS_DEC, 64, (1.0, 2.0, 3.0), 150, 50),   # int16 min-sum: exact by construction after the quantiser
+    (IMS_DEC, 20, (3.0,), 100, 50),
+    (IMS_DEC, 126, (2.0,), 24, 50),
 ])
 def test_random_batches_against_oracle(L, torch, dec_id, M, snrs, frames, maxiter):
     H = relift(load_base_matrix(), M)
@@ -334,7 +337,7 @@ def test_exact_replay_harness_equals_the_sequential_harness(L, dec_id, M, snr, m
         assert res.nde == 112 and res.experiment == 2001   # the FER 0.056 the survey measured with the compiled upstream binary
 
 
-@pytest.mark.parametrize("name", ["ms_m64_1p2", "lms_m64_0p8", "sp_m64_2p0", "ms_m126_1p7", "ms_m1_4p0"])
+@pytest.mark.parametrize("name", ["ms_m64_1p2", "lms_m64_0p8", "sp_m64_2p0", "ms_m126_1p7", "ms_m1_4p0", "ims_m64_2p0"])
 def test_decoders_h_call_surface(L, tmp_path, name):
     """decod_open / hd fill / decod_init / <decoder>(st, st->y, st->decword, ...) / decod_close from a C++ program built
     against include/ldpc/decoders.h, on the reference's golden vectors."""

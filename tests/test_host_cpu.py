@@ -58,6 +58,7 @@ def test_compat_layer_builds_and_exports_upstream_surface():
                  "min_sum_decod_qc_lm(DEC_STATE*, double*, double*, int, int, double)",
                  "sum_prod_decod_qc_lm(DEC_STATE*, double*, double*, int, int)",
                  "lmin_sum_decod_qc_lm(DEC_STATE*, double*, double*, int, int, double, double)",
+                 "imin_sum_decod_qc_lm(DEC_STATE*, double*, double*, int, int, double, double, int, int)",
                  "ldpc::bp_simulation(", "ldpc_bp_simulation_exact", "DEC_FULL_NAME"):
         assert want in syms, want
 
