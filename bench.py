@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip operating point + FER sweep (profiling runs)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI, the measured configuration); gloo only rehearses the N>1 code path on a box "
+                         "with fewer GPUs than ranks (ranks then share devices and the counters are reduced on the host)")
     args = ap.parse_args()
 
     import torch
@@ -111,11 +114,28 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        sys.exit(f"{world} ranks but {ndev} GPUs: one rank per GPU is required with RCCL")
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+
+    def all_reduce(t, op=None):
+        """in-place sum (or `op`) over ranks; RCCL on the device tensor, or via the host for the gloo rehearsal"""
+        kw = {} if op is None else {"op": op}
+        if args.backend == "nccl":
+            dist.all_reduce(t, **kw)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, **kw)
+            t.copy_(h)
 
     H = ldpc_lib_amd.relift_base_matrix(load_base_matrix(), M)
     B = args.frames
@@ -143,7 +163,7 @@ def main():
         cnt.zero_()
         dec.count_errors(hard, iters, counters=cnt)
         if world > 1:
-            dist.all_reduce(cnt)  # 40-byte message: {nse, nde, nue, frames, sum|iters|}
+            all_reduce(cnt)  # 40-byte message: {nse, nde, nue, frames, sum|iters|}
         tot += cnt
 
     def timed(snr, steps, warmup):
@@ -165,7 +185,7 @@ def main():
         dec.profile(False)
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            all_reduce(t, op=dist.ReduceOp.MAX)
         del batches
         return float(t.item()), tot.cpu().tolist(), kms, klaunch
 
@@ -196,7 +216,7 @@ def main():
             "workload": "files/input32_16.jsonx code (SURVEY Appendix C base matrix 16x32, 112 circulants) lifted to "
                         "(2048,1024) M=64, flooding min-sum alpha=0.8, max 50 iterations, all-zero codeword BPSK/AWGN "
                         f"Eb/N0 {WORST_SNR} dB (every frame runs all 50 iterations), LLR fp64 resident in HBM",
-            "frames_per_gpu_per_step": B, "global_frames_per_step": B * world, "sharding": f"frames x{world}",
+            "frames_per_gpu_per_step": B, "global_frames_per_step": B * world, "sharding": f"frames x{world}", "collective": (args.backend + " all-reduce of 5 int64 counters per step") if world > 1 else None,
             "fer": tot[1] / tot[3], "mean_iters_per_frame": tot[4] / tot[3],
         },
         "roofline": {
@@ -224,7 +244,7 @@ def main():
             s = dec.simulate(float(snr), MAXITER, seed=1, first_frame=rank * B, B=B)
             c = torch.tensor([s["nse"], s["nde"], s["frames"]], dtype=torch.int64, device=dev)
             if world > 1:
-                dist.all_reduce(c)
+                all_reduce(c)
             c = c.cpu().tolist()
             sweep.append({"ebn0_db": float(snr), "fer": c[1] / c[2], "ber": c[0] / c[2] / (N - R), "frames": c[2]})
         out["fer_sweep"] = sweep

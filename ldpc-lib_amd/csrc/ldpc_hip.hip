@@ -91,7 +91,7 @@ struct ldpc_hip_ctx {
     ldpc::FastTab fast_tab;
     // device tables
     int32_t *d_row_start = nullptr, *d_col_start = nullptr;
-    uint32_t *d_edges = nullptr, *d_col_edges = nullptr, *d_col_slot = nullptr;
+    uint32_t *d_edges = nullptr, *d_col_edges = nullptr, *d_col_slot = nullptr, *d_edge_row = nullptr;
     // workspace for ldpc_hip_simulate / decode_host
     double *w_llr = nullptr;
     uint32_t *w_hard = nullptr;
@@ -287,7 +287,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
     } else {
         c->multiwave = true;
         c->F = 1;
-        c->threads = 256;
+        c->threads = ldpc::kSpThreads;
         c->lds_bytes = ldpc::sp_lds_bytes(c->ne, M, c->R, c->N);
         c->kernel_name = "sp_flood_kernel";
         if (c->N > ldpc::kSpNVM * c->threads) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "sum-product: N=%d > %d", c->N, ldpc::kSpNVM * c->threads); }
@@ -304,6 +304,10 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
     if (e == hipSuccess) e = hipMalloc(&c->d_edges, sizeof(uint32_t) * (c->ne + 1));
     if (e == hipSuccess) e = hipMalloc(&c->d_col_edges, sizeof(uint32_t) * (c->ne + 1));
     if (e == hipSuccess) e = hipMalloc(&c->d_col_slot, sizeof(uint32_t) * (c->ne + 1));
+    if (e == hipSuccess) e = hipMalloc(&c->d_edge_row, sizeof(uint32_t) * (c->ne + 1));
+    std::vector<uint32_t> edge_row(c->ne + 1, 0);
+    for (int j = 0; j < rh; ++j) for (int q = row_start[j]; q < row_start[j + 1]; ++q) edge_row[q] = (uint32_t)j;
+    if (e == hipSuccess && c->ne) e = hipMemcpy(c->d_edge_row, edge_row.data(), sizeof(uint32_t) * c->ne, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&c->w_counters, sizeof(unsigned long long) * 8);
     if (e == hipSuccess) e = hipMemcpy(c->d_row_start, row_start.data(), sizeof(int32_t) * (rh + 1), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_col_start, col_start.data(), sizeof(int32_t) * (nh + 1), hipMemcpyHostToDevice);
@@ -327,6 +331,7 @@ void ldpc_hip_close(ldpc_hip_ctx *c) {
     if (c->d_edges) (void)hipFree(c->d_edges);
     if (c->d_col_edges) (void)hipFree(c->d_col_edges);
     if (c->d_col_slot) (void)hipFree(c->d_col_slot);
+    if (c->d_edge_row) (void)hipFree(c->d_edge_row);
     if (c->w_counters) (void)hipFree(c->w_counters);
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete c;
@@ -349,7 +354,7 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
     ldpc::DecArgs a{};
     a.llr = d_llr; a.hard = d_hard; a.iters = d_iters; a.soft_out = d_soft;
     a.row_start = c->d_row_start; a.edges = c->d_edges;
-    a.col_start = c->d_col_start; a.col_edges = c->d_col_edges; a.col_slot = c->d_col_slot;
+    a.col_start = c->d_col_start; a.col_edges = c->d_col_edges; a.col_slot = c->d_col_slot; a.edge_row = c->d_edge_row;
     a.B = B; a.rh = c->rh; a.nh = c->nh; a.M = c->M; a.N = c->N; a.F = c->F;
     a.maxiter = maxiter; a.hard_words = c->hard_words; a.alpha = alpha;
     a.ims_thr = c->ims_thr; a.ims_qbits = c->ims_qbits; a.ims_dbits = c->ims_dbits;

@@ -41,7 +41,8 @@ struct DecArgs {
     const uint32_t *edges;    // [ne]  (block column << 16) | shift, row-major order (rows asc, columns asc)
     const int32_t *col_start; // [nh+1]           (sum-product only)
     const uint32_t *col_edges;// [ne] (block row << 16) | shift, column-major order (columns asc, rows asc)
-    const uint32_t *col_slot; // [ne] for the q-th entry of a column: index of that edge inside its block row
+    const uint32_t *col_slot; // [ne] for the q-th entry of a column: row-major id of that edge
+    const uint32_t *edge_row; // [ne] block row of each row-major edge
     long long B;
     int rh, nh, M, N, F, maxiter, hard_words;
     double alpha;
