@@ -360,4 +360,200 @@ __device__ __forceinline__ void lms_body(const SpecArgs &a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Likelihood-ratio sum-product (upstream sum_prod_decod_qc_lm, decoders.cpp:1923-2185; semantics SURVEY Appendix
+// A.2), code-specialised, for liftings that are a multiple of 64.  One frame per workgroup of SPW = 8 wavefronts.
+// The expensive operations are the three fp64 divisions per edge and iteration; the block columns (x 64-lane chunks)
+// are dealt to the 8 waves at compile time, heaviest first to the least loaded wave, so every wave carries the same
+// number of edges whatever the column weights are (this code has weights 2, 3 and 14).  Phases per iteration:
+//   A  (column units)  AA_u = yd * prod_{other edges of the column, rows ascending} ZZ ; ZZ_u <- (AA_u-1)/(AA_u+1)
+//                      (:2017-2060) -- the prefix of the product is carried in a register and the tail read from the
+//                      not yet overwritten entries, i.e. exactly the reference's multiplication order, in place
+//   B  (row units)     s = 1.0 * prod_{edges of the row, columns ascending} ZZ[e][(n+c) mod M]            (:2047-2050)
+//   C  (column units)  A = s[(t-c) mod M] / ZZ ; A = (1+A)/(1-A) ; clamp [-5.2e-9 (sic), 1.9e8] ; ZZ <- A ; soft *= A
+//   D  (row units)     syndrome = xor over the row's edges of (soft < 1.0)                                (:2129-2149)
+// LDS: ZZ[E][M] fp64 + s[R] fp64 + one hard-decision byte per variable (66 KiB at (2048,1024): two frames per CU);
+// yd and soft of a wave's own columns stay in VGPRs.  exp() is ocml's where the reference uses glibc's (both within
+// 1 ulp), every other operation is exact and in the reference's order: hard decisions and iteration counts are
+// identical on all test sets, a-posteriori ratios agree to rtol 1e-6.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSpWaves = 8;
+
+template <class C>
+struct SpView {  // column view of the code + static work split, all computed at compile time
+    static constexpr int CH = C::M / 64;                 // 64-lane chunks per circulant
+    int row_off[C::RH + 1] = {};                         // row-major edge id of (row j, slot 0)
+    int cw[C::NH] = {};                                  // column weights
+    int ce[C::NH][C::RH] = {};                           // edge ids of a column, rows ascending
+    int cj[C::NH][C::RH] = {};                           // their block rows
+    int cc[C::NH][C::RH] = {};                           // their shifts
+    int col_wave[C::NH * (C::M / 64)] = {};              // wave that owns unit (k, chunk)
+    int col_slot[C::NH * (C::M / 64)] = {};              // index of the unit inside its wave's list
+    int units_max = 0;                                   // max units per wave
+    int ne = 0;
+    constexpr SpView() {
+        for (int j = 0; j < C::RH; ++j) { row_off[j] = ne; ne += C::RW[j]; }
+        row_off[C::RH] = ne;
+        for (int j = 0; j < C::RH; ++j)
+            for (int s = 0; s < C::RW[j]; ++s) {
+                const int k = C::COL[j][s];
+                ce[k][cw[k]] = row_off[j] + s; cj[k][cw[k]] = j; cc[k][cw[k]] = C::SH[j][s];
+                ++cw[k];
+            }
+        int load[kSpWaves] = {}, cnt[kSpWaves] = {};
+        bool used[C::NH * (C::M / 64)] = {};
+        for (int it = 0; it < C::NH * CH; ++it) {         // heaviest remaining unit -> least loaded wave
+            int best = -1;
+            for (int u = 0; u < C::NH * CH; ++u)
+                if (!used[u] && (best < 0 || cw[u / CH] > cw[best / CH])) best = u;
+            int w = 0;
+            for (int x = 1; x < kSpWaves; ++x) if (load[x] < load[w]) w = x;
+            used[best] = true; col_wave[best] = w; col_slot[best] = cnt[w]++; load[w] += cw[best / CH];
+        }
+        for (int x = 0; x < kSpWaves; ++x) if (cnt[x] > units_max) units_max = cnt[x];
+    }
+};
+
+template <class C>
+__device__ __forceinline__ void sp_body(const SpecArgs &a) {
+    static_assert(C::M % 64 == 0, "sp_body: lifting must be a multiple of 64");
+    constexpr SpView<C> V{};
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, R = RH * M, CH = M / 64, T = kSpWaves * 64;
+    constexpr int NE = V.ne, UMAX = V.units_max;
+    extern __shared__ double lds[];
+    char *const zzb = reinterpret_cast<char *>(lds);                        // ZZ[e][t] at e*M*8 + t*8
+    char *const sb = zzb + (size_t)NE * M * 8;                              // s[j][n]
+    unsigned char *const hb = reinterpret_cast<unsigned char *>(sb + (size_t)R * 8);  // [N]
+    int *const flag = reinterpret_cast<int *>(hb + ((N + 15) & ~15));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long fr = blockIdx.x;
+
+    auto mind = [](double x, double y) { return x < y ? x : y; };            // decoders.cpp:104
+    auto maxd = [](double x, double y) { return x < y ? y : x; };            // decoders.cpp:105
+    auto vote = [&](bool fail) -> bool {
+        if (threadIdx.x == 0) *flag = 0;
+        __syncthreads();
+        if (__ballot(fail) != 0ull && lane == 0) atomicOr(flag, 1);
+        __syncthreads();
+        const bool r = *flag != 0;
+        __syncthreads();
+        return r;
+    };
+    // rows (x chunks) are dealt round-robin to the waves: unit (j, ch) -> wave (j*CH + ch) % 8
+    auto syndrome_fail = [&]() -> bool {
+        bool f = false;
+        static_for<0, RH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
+            if (wave == u % kSpWaves) {
+                const int n = ch * 64 + lane;
+                unsigned sy = 0;
+                static_for<0, C::RW[j]>([&](auto S) {
+                    constexpr int s = decltype(S)::value;
+                    int t = n + C::SH[j][s]; if (t >= M) t -= M;
+                    sy ^= hb[C::COL[j][s] * M + t];
+                });
+                f |= sy != 0;
+            }
+        });
+        return f;
+    };
+
+    double yd[UMAX], sf[UMAX];
+    static_for<0, UMAX>([&](auto Q) { yd[decltype(Q)::value] = 1.0; sf[decltype(Q)::value] = 1.0; });
+    static_for<0, NH * CH>([&](auto U) {
+        constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
+        if (wave == V.col_wave[u]) {
+            const int t = ch * 64 + lane;
+            const double yl = maxd(mind(a.llr[fr * N + k * M + t], 20.0), -20.0);   // :1949 INPUT_LIMIT
+            yd[q] = sf[q] = exp(yl);
+            hb[k * M + t] = yd[q] < 1.0;
+            static_for<0, V.cw[k]>([&](auto X) {                                     // :1957-1959
+                *reinterpret_cast<double *>(zzb + (size_t)V.ce[k][decltype(X)::value] * M * 8 + t * 8) = 1.0;
+            });
+        }
+    });
+    __syncthreads();
+
+    int res = -a.maxiter;
+    bool conv = !vote(syndrome_fail());                                              // :1964-2002
+    if (conv) res = 0;
+    for (int iter = 0; !conv && iter < a.maxiter; ++iter) {
+        // ---- phase A
+        static_for<0, NH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u], CW = V.cw[k];
+            if (wave == V.col_wave[u]) {
+                const int t8 = (ch * 64 + lane) * 8;
+                double zo[CW];
+                static_for<0, CW>([&](auto X) {
+                    constexpr int x = decltype(X)::value;
+                    zo[x] = *reinterpret_cast<const double *>(zzb + (size_t)V.ce[k][x] * M * 8 + t8);
+                });
+                double prefix = yd[q];
+                static_for<0, CW>([&](auto X) {
+                    constexpr int x = decltype(X)::value;
+                    double AA = prefix;                                               // :2027-2041, ascending rows
+                    static_for<x + 1, CW>([&](auto W2) { AA *= zo[decltype(W2)::value]; });
+                    *reinterpret_cast<double *>(zzb + (size_t)V.ce[k][x] * M * 8 + t8) = (AA - 1) / (AA + 1);  // :2044
+                    prefix *= zo[x];
+                });
+            }
+        });
+        __syncthreads();
+        // ---- phase B
+        static_for<0, RH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
+            if (wave == u % kSpWaves) {
+                const int n = ch * 64 + lane;
+                double s = 1.0;                                                       // :2010
+                static_for<0, C::RW[j]>([&](auto S) {
+                    constexpr int sl = decltype(S)::value;
+                    int t = n + C::SH[j][sl]; if (t >= M) t -= M;
+                    s *= *reinterpret_cast<const double *>(zzb + (size_t)(V.row_off[j] + sl) * M * 8 + t * 8);  // :2047-2050
+                });
+                *reinterpret_cast<double *>(sb + (size_t)(j * M + n) * 8) = s;
+            }
+        });
+        __syncthreads();
+        // ---- phase C
+        static_for<0, NH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u], CW = V.cw[k];
+            if (wave == V.col_wave[u]) {
+                const int t = ch * 64 + lane;
+                double soft = yd[q];                                                  // :2011
+                static_for<0, CW>([&](auto X) {
+                    constexpr int x = decltype(X)::value;
+                    int nn = t - V.cc[k][x]; if (nn < 0) nn += M;                    // rotate by M-circ (:2113)
+                    double *zp = reinterpret_cast<double *>(zzb + (size_t)V.ce[k][x] * M * 8 + t * 8);
+                    double A = *reinterpret_cast<const double *>(sb + (size_t)(V.cj[k][x] * M + nn) * 8) / *zp;
+                    A = (1 + A) / (1 - A);
+                    A = maxd(mind(A, 1.9e+8), -5.2e-9);                              // :2120 (negative lower clamp is upstream's)
+                    *zp = A;
+                    soft *= A;
+                });
+                sf[q] = soft;
+                hb[k * M + t] = soft < 1.0;
+            }
+        });
+        __syncthreads();
+        // ---- phase D
+        if (!vote(syndrome_fail())) { conv = true; res = iter + 1; }                 // :2151-2166
+    }
+
+    if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
+    if (a.hard) {
+        for (int w = threadIdx.x; w < N / 32; w += T) {
+            u32 bits = 0;
+            for (int b = 0; b < 32; ++b) bits |= (u32)hb[32 * w + b] << b;
+            a.hard[fr * (N / 32) + w] = bits;
+        }
+    }
+    if (a.soft_out) {
+        static_for<0, NH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
+            if (wave == V.col_wave[u]) a.soft_out[fr * N + k * M + ch * 64 + lane] = sf[q];
+        });
+    }
+}
+
 }  // namespace ldpc_spec

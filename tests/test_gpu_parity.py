@@ -396,3 +396,22 @@ def test_layered_min_sum_specialised_instances(L, torch, M, frames):
     for Maot in (64, 512):
         with L.LdpcHip(LMS_DEC, relift(load_base_matrix(), Maot), Maot) as dec:
             assert "ahead of time" in dec.kernel_name
+
+
+def test_sum_product_specialised_instances(L, torch):
+    """code-specialised sum-product: ahead-of-time instance for the example code, hiprtc instance for another code."""
+    H = relift(load_base_matrix(), 64)
+    with L.LdpcHip(SP_DEC, H, 64) as dec:
+        assert "sp_spec" in dec.kernel_name and "ahead of time" in dec.kernel_name
+    H2 = _other_m64_code()
+    llr = np.concatenate([awgn_llr(H2, 64, s, 70 + i, 40) for i, s in enumerate((1.2, 2.2))])
+    o = Oracle(H2, 64)
+    d_ref, it_ref, _ = o.decode(SP_DEC, llr, 50, 0)
+    s_ref, _, _ = o.decode(SP_DEC, llr, 50, 1)
+    with L.LdpcHip(SP_DEC, H2, 64) as dec:
+        assert "sp_spec_jit" in dec.kernel_name, dec.kernel_name
+        hard, iters, soft = dec.decode(torch.from_numpy(llr).cuda(), 50, want_soft=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(iters.cpu().numpy(), it_ref)
+        assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
+        np.testing.assert_allclose(soft.cpu().numpy(), s_ref, rtol=SP_RTOL)
