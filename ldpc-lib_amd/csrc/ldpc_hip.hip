@@ -67,6 +67,13 @@ __global__ void __launch_bounds__(512, 2) sp_spec_appendix_c_m64_occ2_kernel(con
     ldpc_spec::sp_body<ldpc_spec::CodeAppendixCM64>(a);
 }
 
+__global__ void __launch_bounds__(64, 1) tasp_spec_appendix_c_m64_kernel(const ldpc_spec::SpecArgs a) {
+    ldpc_spec::tasp_body<ldpc_spec::CodeAppendixCM64>(a);
+}
+__global__ void __launch_bounds__(128, 1) tasp_spec_appendix_c_m126_kernel(const ldpc_spec::SpecArgs a) {
+    ldpc_spec::tasp_body<ldpc_spec::CodeAppendixCM126>(a);
+}
+
 template <class FC>
 static bool same_code(int rh, int nh, int M, const std::vector<int32_t> &row_start, const std::vector<uint32_t> &edges) {
     bool same = rh == FC::RH && nh == FC::NH && M == FC::M;
@@ -169,8 +176,9 @@ int ldpc_hip_device_count(void) {
 int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int device, ldpc_hip_ctx **out) {
     if (out) *out = nullptr;
     if (!out || !hd || rh <= 0 || nh <= 0 || M <= 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_open: bad argument");
-    if (decoder_id != LDPC_HIP_MS_DEC && decoder_id != LDPC_HIP_LMS_DEC && decoder_id != LDPC_HIP_SP_DEC && decoder_id != LDPC_HIP_IMS_DEC)
-        return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_open: decoder id %d is not built (built: SP=1, MS=3, IMS=4, LMS=8)", decoder_id);
+    if (decoder_id != LDPC_HIP_MS_DEC && decoder_id != LDPC_HIP_LMS_DEC && decoder_id != LDPC_HIP_SP_DEC && decoder_id != LDPC_HIP_IMS_DEC &&
+        decoder_id != LDPC_HIP_TASP_DEC)
+        return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_open: decoder id %d is not built (built: SP=1, MS=3, IMS=4, TASP=7, LMS=8)", decoder_id);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(LDPC_HIP_EINVAL, "ldpc_hip_open: device %d of %d", device, ndev);
@@ -213,7 +221,33 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
 
     // what the kernels were instantiated for
     if (M >= 65536 || nh >= 65536) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "M and nh must be < 65536"); }
-    if (decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || decoder_id == LDPC_HIP_IMS_DEC) {
+    if (decoder_id == LDPC_HIP_TASP_DEC) {
+        // TDMP sum-product exists as code-specialised instances only (per-edge state in VGPRs of the check lane)
+        int min_rw = 1 << 30, regs = 0;
+        for (int j = 0; j < rh; ++j) { const int rw = row_start[j + 1] - row_start[j]; min_rw = rw < min_rw ? rw : min_rw; regs += 2 * rw; }
+        if (M > 256 || min_rw < 2 || regs > 288 || sizeof(double) * (size_t)c->N + 16 > 64 * 1024) {
+            delete c;
+            return fail(LDPC_HIP_EUNSUPPORTED, "TASP: needs M <= 256 (got %d), every block row of weight >= 2 (min %d), <= 144 circulants (got %d) and "
+                        "N <= 8190 (got %d)", M, min_rw, regs / 2, nh * M);
+        }
+        c->F = 1; c->multiwave = M > 64;
+        c->spec_threads = c->threads = ((M + 63) / 64) * 64;
+        c->lds_bytes = sizeof(double) * (size_t)c->N + 16;
+        if (same_code<ldpc_spec::CodeAppendixCM64>(rh, nh, M, row_start, edges) ||
+            same_code<ldpc_spec::CodeAppendixCM126>(rh, nh, M, row_start, edges)) {
+            c->spec_aot = true;
+            c->kernel_name = M == 64 ? "tasp_spec_appendix_c_m64_kernel (ahead of time)" : "tasp_spec_appendix_c_m126_kernel (ahead of time)";
+        } else {
+            std::vector<std::vector<std::pair<int, int>>> rows(rh);
+            for (int j = 0; j < rh; ++j)
+                for (int e2 = row_start[j]; e2 < row_start[j + 1]; ++e2)
+                    rows[j].emplace_back((int)(edges[e2] >> 16), (int)(edges[e2] & 0xffffu));
+            std::string jerr;
+            c->jit = ldpc_jit::get(device, "tasp_body", rows, nh, M, jerr);
+            if (!c->jit) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "TASP needs a hiprtc instance for this base matrix: %s", jerr.c_str()); }
+            c->kernel_name = "tasp_spec_jit (hiprtc)";
+        }
+    } else if (decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || decoder_id == LDPC_HIP_IMS_DEC) {
         if (rh > kRHM) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "rh=%d > %d block rows", rh, kRHM); }
         if (c->max_rw > kRWM) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "row weight %d > %d", c->max_rw, kRWM); }
         if ((decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_IMS_DEC) && nh > kNHM) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "nh=%d > %d block columns", nh, kNHM); }
@@ -449,6 +483,18 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
             hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
         }
         break;
+    case LDPC_HIP_TASP_DEC: {
+        ldpc_spec::SpecArgs sa{};
+        sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
+        if (B > 0x7fffffffLL) return fail(LDPC_HIP_EINVAL, "batch too large");
+        if (c->spec_aot && c->M == 64) hipLaunchKernelGGL(tasp_spec_appendix_c_m64_kernel, dim3((unsigned)B), dim3(64), c->lds_bytes, stream, sa);
+        else if (c->spec_aot) hipLaunchKernelGGL(tasp_spec_appendix_c_m126_kernel, dim3((unsigned)B), dim3(128), c->lds_bytes, stream, sa);
+        else {
+            void *kargs[] = {&sa};
+            HIP_TRY(hipModuleLaunchKernel(c->jit->fn, (unsigned)B, 1, 1, (unsigned)c->spec_threads, 1, 1, (unsigned)c->lds_bytes, stream, kargs, nullptr));
+        }
+        break;
+    }
     case LDPC_HIP_IMS_DEC:
         if (c->multiwave) {
             auto k = ldpc::ims_flood_kernel<kRHM, kNHM, true>;
@@ -499,6 +545,8 @@ int ldpc_hip_decode_host(ldpc_hip_ctx *c, double *llr, long long B, int maxiter,
     if (B == 0) return 0;
     if (int rc = set_device(c)) return rc;
     const bool sp = c->decoder_id == LDPC_HIP_SP_DEC;
+    const bool tasp = c->decoder_id == LDPC_HIP_TASP_DEC;
+    if (tasp) decision = 0;  // upstream ignores `decision` for this decoder: the result is always hard (decoders.cpp:2737-2738)
     const bool need_soft = decision != 0 || (sp && clobber_sp_input);
     if (int rc = ensure_workspace(c, B, need_soft)) return rc;
     const size_t nllr = (size_t)B * c->N;
@@ -525,6 +573,14 @@ int ldpc_hip_decode_host(ldpc_hip_ctx *c, double *llr, long long B, int maxiter,
         }
     }
     if (sp && clobber_sp_input) std::memcpy(llr, soft.data(), sizeof(double) * nllr);  // decoders.cpp:1950,2124
+    if (tasp && clobber_sp_input) {  // decoders.cpp:2611-2618: soft[] is left holding P(bit = 1) of the channel
+        for (size_t i = 0; i < nllr; ++i) {
+            const double x = llr[i] * 0.5;
+            const double y = x < 20.0 ? (x < -20.0 ? -20.0 : x) : 20.0;
+            const double e0 = std::exp(y), e1 = std::exp(-y);
+            llr[i] = e1 / (e0 + e1);
+        }
+    }
     return 0;
 }
 
@@ -554,7 +610,7 @@ int ldpc_hip_awgn_llr_dev(ldpc_hip_ctx *c, double snr_db, int modulation_type, i
     if (int rc = awgn_sigma(c, snr_db, modulation_type, punctured_blocks, &a.sigma)) return rc;
     a.llr = d_llr; a.B = B; a.first_frame = first_frame; a.N = c->N;
     a.punct_start = c->N - c->M * punctured_blocks;
-    a.punct_val = c->decoder_id == LDPC_HIP_SP_DEC ? 0.0 : 0.5;  // :700 (sic)
+    a.punct_val = (c->decoder_id == LDPC_HIP_SP_DEC || c->decoder_id == LDPC_HIP_TASP_DEC) ? 0.0 : 0.5;  // :700 (sic), out_type :451-466
     a.seed = seed;
     const long long total = B * (long long)((c->N + 1) / 2);
     long long blocks = (total + 255) / 256;

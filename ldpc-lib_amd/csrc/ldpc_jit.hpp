@@ -123,7 +123,7 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
     hs << hf.rdbuf();
     const std::string hdr = hs.str();
     const std::string src = "#include \"ldpc_ms_spec.hpp\"\nnamespace {\n" + code +
-                            "}\nextern \"C\" __global__ void __launch_bounds__(" + std::to_string(threads) + (std::string(body) == "sp_body" ? ", 4" : ", 2") + ") spec_jit(const ldpc_spec::SpecArgs a) {\n"
+                            "}\nextern \"C\" __global__ void __launch_bounds__(" + std::to_string(threads) + (std::string(body) == "sp_body" ? ", 4" : std::string(body) == "tasp_body" ? ", 1" : ", 2") + ") spec_jit(const ldpc_spec::SpecArgs a) {\n"
                             "    ldpc_spec::" + body + "<Code>(a);\n}\n";
     hiprtcProgram prog = nullptr;
     const char *hdr_src[] = {hdr.c_str()};

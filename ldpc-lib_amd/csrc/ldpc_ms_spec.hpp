@@ -556,4 +556,142 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// TDMP ("turbo-decoding message passing") sum-product in the probability domain -- upstream
+// tdmp_sum_prod_gf2_decod_qc_lm (decoders.cpp:2584-2744, map_bin :2191-2228), decoder id 7, the decoder_type of every
+// shipped scenario file.  Layered like lms_body: block rows are sequential, one frame per workgroup of ceil(M/64)
+// waves, a-posteriori probabilities P(bit=1) in LDS.  The per-edge state Z (one fp64 per edge and check, which the
+// reference keeps in an R x max-row-weight matrix) lives in VGPRs of the check lane -- 2 VGPRs per circulant, so
+// this kernel runs one wave per SIMD (<= 512 VGPRs) and supports liftings up to 256.
+// Two fp64 divisions per edge and iteration.  The channel transform uses exp() (ocml here, glibc upstream), so
+// probabilities agree to rounding (rtol 1e-6 after 15-50 iterations); hard decisions and the returned step count are
+// identical on all test sets.  As upstream, the result is always the hard decision (`decision` is dead, :2737).
+// ---------------------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void tasp_body(const SpecArgs &a) {
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, W = (M + 63) / 64;
+    constexpr double T = 0.0001, TT = 0;                                   // :2597-2598
+    extern __shared__ double lds[];                                         // [N] soft_out, then one flag word
+    char *const ldsb = reinterpret_cast<char *>(lds);
+    int *const flag = reinterpret_cast<int *>(ldsb + (size_t)N * 8);
+    const int n = threadIdx.x;
+    const bool valid = (M % 64 == 0) || n < M;
+    const u32 n8 = (u32)(valid ? n : 0) * 8u;
+    const long long fr = blockIdx.x;
+
+    auto rot = [&](u32 base, auto S) -> u32 {
+        constexpr int c = decltype(S)::value;
+        if constexpr (c == 0) return base;
+        else if constexpr ((M & (M - 1)) == 0) return (base + 8u * (u32)c) & (u32)(8 * M - 1);
+        else { const u32 t = base + 8u * (u32)c; return t >= (u32)(8 * M) ? t - (u32)(8 * M) : t; }
+    };
+    auto vote = [&](bool fail) -> bool {
+        if constexpr (W == 1) return __ballot(fail) != 0ull;
+        else {
+            if (threadIdx.x == 0) *flag = 0;
+            __syncthreads();
+            if (__ballot(fail) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+            __syncthreads();
+            const bool r = *flag != 0;
+            __syncthreads();
+            return r;
+        }
+    };
+    auto syndrome_fail = [&]() -> bool {                                    // check_syndrome_thr :2274-2306, thr 0.5
+        bool f = false;
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            u32 sy = 0, nb = n8;
+            asm volatile("" : "+v"(nb));
+            static_for<0, C::RW[j]>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                sy ^= (u32)(*reinterpret_cast<const double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M)) > 0.5);
+            });
+            f |= sy != 0;
+        });
+        return valid && f;
+    };
+    auto mind = [](double x, double y) { return x < y ? x : y; };
+    auto maxd = [](double x, double y) { return x < y ? y : x; };
+
+    if (valid) {
+        static_for<0, NH>([&](auto K) {                                     // :2611-2618
+            constexpr int k = decltype(K)::value;
+            const double x = a.llr[fr * N + k * M + n] * 0.5;
+            const double y = maxd(mind(x, 20.0), -20.0);
+            const double e0 = exp(y), e1 = exp(-y);
+            *reinterpret_cast<double *>(ldsb + n8 + k * (8 * M)) = e1 / (e0 + e1);
+        });
+    }
+    double Z[RH][C::WMAX];
+    static_for<0, RH>([&](auto J) {
+        static_for<0, C::RW[decltype(J)::value]>([&](auto S) { Z[decltype(J)::value][decltype(S)::value] = 0.5; });  // :2637
+    });
+    if constexpr (W > 1) __syncthreads();
+
+    int res = 0;
+    bool fail = vote(syndrome_fail());                                      // :2653-2660: already a codeword -> 0
+    int steps = 0;
+    while (fail && steps < a.maxiter) {
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int RW = C::RW[j];
+            static_assert(RW >= 2, "tasp_body: map_bin needs at least two edges per check");
+            u32 nb = n8;
+            asm volatile("" : "+v"(nb));
+            double y[RW], q[RW], P[RW], SF[RW], SB[RW];
+            static_for<0, RW>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                const double x = *reinterpret_cast<const double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M));
+                const double aa = Z[j][s];
+                double v = x * (1.0 - aa) / (aa + x - 2.0 * aa * x);        // :2686 rho = gamma - lambda
+                if (v < TT) v = TT;                                          // :2694-2695
+                if (v > 1 - TT) v = 1 - TT;
+                y[s] = v;
+                P[s] = 1 - 2 * v;                                            // map_bin :2206
+            });
+            SF[0] = P[0];                                                    // :2209-2216
+            static_for<1, RW - 1>([&](auto I) { constexpr int i = decltype(I)::value; SF[i] = P[i] * SF[i - 1]; });
+            SB[RW - 1] = P[RW - 1];
+            static_for<0, RW - 2>([&](auto I) { constexpr int i = RW - 2 - decltype(I)::value; SB[i] = P[i] * SB[i + 1]; });
+            q[0] = (1 - SB[1]) / 2;                                          // :2219-2227
+            static_for<1, RW - 1>([&](auto I) { constexpr int i = decltype(I)::value; q[i] = (1 - SF[i - 1] * SB[i + 1]) / 2; });
+            q[RW - 1] = (1 - SF[RW - 2]) / 2;
+            static_for<0, RW>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                double v = q[s];
+                if (v < T) v = T;                                            // :2703-2704
+                if (v > 1.0 - T) v = 1.0 - T;
+                Z[j][s] = v;
+                const double g = y[s] * v / (1.0 - y[s] - v + 2 * y[s] * v);  // :2716 gamma = rho + lambda
+                if (valid) *reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M)) = g;
+            });
+            if constexpr (W > 1) __syncthreads();
+            else __builtin_amdgcn_sched_barrier(0);
+        });
+        fail = vote(syndrome_fail());                                        // :2723 (only the value after the last layer counts)
+        steps = steps + 1;
+    }
+    res = fail ? -steps : steps;                                             // :2740-2743 (0 when the input was a codeword)
+
+    if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
+    if (a.hard) {
+        constexpr int HW = (N + 31) / 32;
+        for (int w = threadIdx.x; w < HW; w += W * 64) {
+            u32 bits = 0;
+            for (int b = 0; b < 32; ++b) {
+                const int v = 32 * w + b;
+                if (v < N) bits |= (u32)(*reinterpret_cast<const double *>(ldsb + (size_t)v * 8) > 0.5) << b;
+            }
+            a.hard[fr * HW + w] = bits;
+        }
+    }
+    if (a.soft_out && valid) {
+        static_for<0, NH>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            a.soft_out[fr * N + k * M + n] = *reinterpret_cast<const double *>(ldsb + n8 + k * (8 * M));
+        });
+    }
+}
+
 }  // namespace ldpc_spec

@@ -11,7 +11,7 @@ csrc/compat/; this module is its throughput-mode sibling.
 """
 import numpy as np
 
-from .binding import DEC_IMS, DEC_LMS, DEC_MS, DEC_SP, LdpcHip, LdpcHipError
+from .binding import DEC_IMS, DEC_LMS, DEC_MS, DEC_SP, DEC_TASP, LdpcHip, LdpcHipError
 
 MODULATION_SKIP, MODULATION_QAM4, MODULATION_QAM16 = 0, 1, 2  # modulation.h:4-11
 

@@ -383,6 +383,98 @@ int orc_sum_prod(orc_code *c, double *soft, double *decword, int maxiter, int de
     return -iter;                                 /* :2184 */
 }
 
+
+/* ---------------------------------------------------------------------------------------------
+ * TDMP (layered) sum-product in the probability domain: decoders.cpp:2584-2744, map_bin :2191-2228,
+ * check_syndrome_thr :2274-2306.
+ * ------------------------------------------------------------------------------------------- */
+static int orc_syndrome_thr(const orc_code *c, const double *p, double thr) {
+    int e, n, M = c->M, parity = 0;
+    memset(c->synd, 0, c->R);
+    for (e = 0; e < c->ne; e++) {
+        const double *col = p + c->e_col[e] * M;
+        unsigned char *sy = c->synd + c->e_row[e] * M;
+        int sh = c->e_shift[e];
+        for (n = 0; n < M; n++) sy[n] ^= (col[ROT(n, sh, M)] > thr);
+    }
+    for (n = 0; n < c->R; n++) parity |= c->synd[n];
+    return parity;
+}
+
+/* :2191-2228 with step == 1; rw >= 2 */
+static void orc_map_bin(double *a, int rw, double *P, double *SF, double *SB) {
+    int i;
+    for (i = 0; i < rw; i++) P[i] = 1 - 2 * a[i];
+    SB[0] = 1.0; SF[rw - 1] = 0.0;
+    SF[0] = P[0];
+    for (i = 1; i < rw - 1; i++) SF[i] = P[i] * SF[i - 1];
+    SB[rw - 1] = P[rw - 1];
+    for (i = rw - 2; i > 0; i--) SB[i] = P[i] * SB[i + 1];
+    a[0] = (1 - SB[1]) / 2;
+    for (i = 1; i < rw - 1; i++) { double Z = SF[i - 1] * SB[i + 1]; a[i] = (1 - Z) / 2; }
+    a[rw - 1] = (1 - SF[rw - 2]) / 2;
+}
+
+int orc_tdmp_sum_prod(orc_code *c, double *soft, double *decword, int maxsteps, double *post_out) {
+    const int M = c->M, N = c->N, rh = c->rh;
+    const double T = 0.0001, TT = 0; /* :2597-2598 */
+    double *so = c->soft;             /* soft_out */
+    double *Zs = c->ZZ;               /* per-edge state, [edge block][check n] (reference: Z[check][cnt]) */
+    double y[64], a[64], P[64], SF[64], SB[64];
+    int v, e, j, n, steps, synd;
+
+    for (v = 0; v < N; v++) {         /* :2611-2618 */
+        double x = soft[v] * 0.5;
+        double yy = orc_maxd(orc_mind(x, 20.0), -20.0);
+        double e0 = exp(yy), e1 = exp(-yy);
+        soft[v] = e1 / (e0 + e1);
+    }
+    for (e = 0; e < c->ne; e++) for (n = 0; n < M; n++) Zs[(size_t)e * M + n] = 0.5;  /* :2620-2641 */
+    for (v = 0; v < N; v++) so[v] = soft[v];
+    synd = orc_syndrome_thr(c, so, 0.5);  /* :2653 */
+    if (synd == 0) {
+        for (v = 0; v < N; v++) decword[v] = so[v] > 0.5;
+        if (post_out) memcpy(post_out, so, sizeof(double) * N);
+        return 0;
+    }
+    steps = 0;
+    while (steps < maxsteps) {
+        for (j = 0; j < rh; j++) {    /* layers, :2668-2724 */
+            const int e0 = c->row_start[j], rw = c->row_start[j + 1] - e0;
+            for (n = 0; n < M; n++) {
+                int s;
+                for (s = 0; s < rw; s++) {
+                    const int idx = c->e_col[e0 + s] * M + ROT(n, c->e_shift[e0 + s], M);
+                    const double x = so[idx], aa = Zs[(size_t)(e0 + s) * M + n];
+                    y[s] = x * (1.0 - aa) / (aa + x - 2.0 * aa * x);          /* :2686 */
+                }
+                for (s = 0; s < rw; s++) {
+                    if (y[s] < TT) y[s] = TT;
+                    if (y[s] > 1 - TT) y[s] = 1 - TT;
+                    a[s] = y[s];
+                }
+                orc_map_bin(a, rw, P, SF, SB);
+                for (s = 0; s < rw; s++) {
+                    if (a[s] < T) a[s] = T;
+                    if (a[s] > 1.0 - T) a[s] = 1.0 - T;
+                }
+                for (s = 0; s < rw; s++) {
+                    const int idx = c->e_col[e0 + s] * M + ROT(n, c->e_shift[e0 + s], M);
+                    Zs[(size_t)(e0 + s) * M + n] = a[s];
+                    so[idx] = y[s] * a[s] / (1.0 - y[s] - a[s] + 2 * y[s] * a[s]);  /* :2716 */
+                }
+            }
+        }
+        synd = orc_syndrome_thr(c, so, 0.5);  /* the reference recomputes it after every layer; only the last one counts (:2723) */
+        steps = steps + 1;
+        if (synd == 0) break;
+    }
+    for (v = 0; v < N; v++) decword[v] = so[v] > 0.5;  /* :2737-2738 */
+    if (post_out) memcpy(post_out, so, sizeof(double) * N);
+    if (synd == 1) steps = -steps;
+    return steps;
+}
+
 /* ---------------------------------------------------------------------------------------------
  * Integer min-sum: decoders.cpp:5430-5690 (MS_MUL_CORRECTION, MS_ALPHA_FPP = 4, decoders.h:13-14)
  * ------------------------------------------------------------------------------------------- */

@@ -51,6 +51,13 @@ int orc_sum_prod(orc_code *c, double *soft, double *decword, int maxiter, int de
 int orc_imin_sum(orc_code *c, const double *y, double *decword, int maxsteps, int decision,
                  double alpha, double thr, int qbits, int dbits);
 
+/* decoders.cpp:2584-2744 tdmp_sum_prod_gf2_decod_qc_lm ("TASP", decoder id 7: the decoder_type of every shipped
+ * scenario file): layered sum-product in the probability domain.  soft[] is CLOBBERED with P(bit=1) of the channel
+ * (:2611-2618).  decword is ALWAYS the hard decision soft_out > 0.5 (the `decision` argument is dead, :2737-2738);
+ * post_out (optional, may be NULL) receives the final a-posteriori probabilities for tolerance checks.
+ * returns 0 if the input already is a codeword, steps (>0) when the syndrome cleared, -steps otherwise. */
+int orc_tdmp_sum_prod(orc_code *c, double *soft, double *decword, int maxsteps, double *post_out);
+
 /* Syndrome of hard decisions (soft<0) : decoders.cpp:793-814 check_syndrome. returns 1 if any check fails. */
 int orc_syndrome_nonzero(const orc_code *c, const double *soft);
 

@@ -17,7 +17,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from ldpc_testlib import (GOLDEN_DIR, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, Reference, awgn_llr, load_base_matrix,  # noqa: E402
+from ldpc_testlib import (GOLDEN_DIR, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Reference, awgn_llr, load_base_matrix,  # noqa: E402
                           oracle_lib, pack_bits, ref_lib, relift, _as_double_p)
 
 SETS = [
@@ -38,7 +38,12 @@ SETS = [
     ("sp_m64_1p2",     SP_DEC,  64,  1.2, 16, 50, 4),
     ("sp_m1_4p0",      SP_DEC,  1,   4.0, 64, 20, 8),
     ("ims_m64_2p0",    IMS_DEC, 64,  2.0, 16, 50, 4),
+    ("tasp_m126_1p7",  TASP_DEC, 126, 1.7, 12, 15, 2),  # the shipped search scenario: decoder_type 7, M 126, 15 iterations, 1.7 dB
+    ("tasp_m64_1p7",   TASP_DEC, 64,  1.7, 24, 15, 4),
+    ("tasp_m64_1p0",   TASP_DEC, 64,  1.0, 12, 50, 2),
+    ("tasp_m1_4p0",    TASP_DEC, 1,   4.0, 64, 20, 8),
 ]
+ONLY = set(sys.argv[1:])  # optional: regenerate just the named sets
 
 
 def main():
@@ -47,6 +52,8 @@ def main():
     H0 = load_base_matrix()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     for name, dec, M, snr, frames, maxiter, soft_frames in SETS:
+        if ONLY and name not in ONLY:
+            continue
         H = relift(H0, M)
         llr = awgn_llr(H, M, snr, 1, frames)
         ref = Reference(dec, H, M)
@@ -61,6 +68,8 @@ def main():
         print(f"{name}: frames={frames} iters={it0.tolist()[:12]}... fail={(it0 < 0).sum()} errbits={int((dec0 != 0).sum())}")
         ref.close()
 
+    if ONLY:
+        return
     # QAM front end (QAM_modulator.cpp / QAM_demodulator.cpp), function level.
     rlib = ref_lib()
     rng = np.random.RandomState(7)
