@@ -53,6 +53,12 @@ __global__ void __launch_bounds__(64, 2) ms_spec_appendix_c_m64_kernel(const ldp
     ldpc_spec::ms_m64_body<ldpc_spec::CodeAppendixCM64>(a);
 }
 
+__global__ void __launch_bounds__(128, 2) ms_spec_appendix_c_m126_kernel(const ldpc_spec::SpecArgs a) {
+    ldpc_spec::ms_body<ldpc_spec::CodeAppendixCM126>(a);
+}
+__global__ void __launch_bounds__(512, 2) ms_spec_appendix_c_m512_kernel(const ldpc_spec::SpecArgs a) {
+    ldpc_spec::ms_body<ldpc_spec::CodeAppendixCM512>(a);
+}
 __global__ void __launch_bounds__(64, 2) lms_spec_appendix_c_m64_kernel(const ldpc_spec::SpecArgs a) {
     ldpc_spec::lms_body<ldpc_spec::CodeAppendixCM64>(a);
 }
@@ -304,6 +310,27 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
                 }
             }
         }
+        if (decoder_id == LDPC_HIP_MS_DEC && M != 64 && M >= 48 && all_cols_used && c->fast_variant == 2 && nh <= 64 && c->max_rw <= 16 &&
+            sizeof(double) * (size_t)c->N + 16 <= 160 * 1024) {
+            // code-specialised flooding min-sum for liftings other than 64: one frame per workgroup of ceil(M/64) waves
+            const char *jenv = getenv("LDPC_HIP_JIT");
+            c->spec_threads = ((M + 63) / 64) * 64;
+            if (same_code<ldpc_spec::CodeAppendixCM126>(rh, nh, M, row_start, edges) ||
+                same_code<ldpc_spec::CodeAppendixCM512>(rh, nh, M, row_start, edges)) {
+                c->spec_aot = true;
+                c->kernel_name = M == 126 ? "ms_spec_appendix_c_m126_kernel (ahead of time)" : "ms_spec_appendix_c_m512_kernel (ahead of time)";
+            } else if (!jenv || atoi(jenv) != 0) {
+                std::vector<std::vector<std::pair<int, int>>> rows(rh);
+                for (int j = 0; j < rh; ++j)
+                    for (int e = row_start[j]; e < row_start[j + 1]; ++e)
+                        rows[j].emplace_back((int)(edges[e] >> 16), (int)(edges[e] & 0xffffu));
+                std::string jerr;
+                c->jit = ldpc_jit::get(device, "ms_body", rows, nh, M, jerr);
+                if (c->jit) c->kernel_name = "ms_spec_jit (hiprtc, multi-wave)";
+                else fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", jerr.c_str(), c->kernel_name.c_str());
+            }
+            if (c->spec_aot || c->jit) c->lds_bytes = sizeof(double) * (size_t)c->N + 16;
+        }
         if (decoder_id == LDPC_HIP_LMS_DEC && M >= 48 && all_cols_used && c->fast_variant == 2 &&
             sizeof(double) * (size_t)c->N + 16 <= 160 * 1024) {
             // code-specialised layered min-sum: one frame per workgroup of ceil(M/64) waves
@@ -439,11 +466,17 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
         if (c->spec_aot || c->jit) {
             ldpc_spec::SpecArgs sa{};
             sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
-            if (c->spec_aot) {
+            if (c->spec_aot && c->M == 64) {
                 hipLaunchKernelGGL(ms_spec_appendix_c_m64_kernel, dim3((unsigned)B), dim3(64), c->lds_bytes, stream, sa);
+            } else if (c->spec_aot && c->M == 126) {
+                hipLaunchKernelGGL(ms_spec_appendix_c_m126_kernel, dim3((unsigned)B), dim3(128), c->lds_bytes, stream, sa);
+            } else if (c->spec_aot) {
+                if (int rc = set_lds_limit(ms_spec_appendix_c_m512_kernel, c->lds_bytes)) return rc;
+                hipLaunchKernelGGL(ms_spec_appendix_c_m512_kernel, dim3((unsigned)B), dim3(512), c->lds_bytes, stream, sa);
             } else {
                 void *kargs[] = {&sa};
-                HIP_TRY(hipModuleLaunchKernel(c->jit->fn, (unsigned)B, 1, 1, 64, 1, 1, (unsigned)c->lds_bytes, stream, kargs, nullptr));
+                HIP_TRY(hipModuleLaunchKernel(c->jit->fn, (unsigned)B, 1, 1, (unsigned)c->spec_threads, 1, 1, (unsigned)c->lds_bytes, stream,
+                                              kargs, nullptr));
             }
         } else if (c->fast_m64) {
             if (c->fast_variant == 1) hipLaunchKernelGGL(ldpc::ms_flood_m64_kernel<false>, grid, block, c->lds_bytes, stream, a, c->fast_tab);

@@ -214,6 +214,160 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Flooding min-sum for ANY lifting M <= 512 (one frame per workgroup of W = ceil(M/64) wavefronts): the algorithm of
+// ms_m64_body with workgroup barriers where several waves share a frame -- after every block row of STATE1 (the next
+// row adds into the same variables and the order of the fp64 adds is part of the result), around STATE2, and in the
+// syndrome vote.  M == 64 codes use ms_m64_body (no barriers, power-of-two rotation).
+// ---------------------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void ms_body(const SpecArgs &a) {
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, W = (M + 63) / 64;
+    constexpr bool POW2 = (M & (M - 1)) == 0;
+    extern __shared__ double lds[];  // [N] soft / acc, then one flag word
+    char *const ldsb = reinterpret_cast<char *>(lds);
+    int *const flag = reinterpret_cast<int *>(ldsb + (size_t)N * 8);
+    const int n = threadIdx.x;
+    const bool valid = (M % 64 == 0) || n < M;
+    const u32 n8 = (u32)(valid ? n : 0) * 8u;
+    const double alpha = a.alpha;
+    const long long fr = blockIdx.x;
+
+    auto rot = [&](u32 base, auto S) -> u32 {
+        constexpr int c = decltype(S)::value;
+        if constexpr (c == 0) return base;
+        else if constexpr (POW2) return (base + 8u * (u32)c) & (u32)(8 * M - 1);
+        else { const u32 t = base + 8u * (u32)c; return t >= (u32)(8 * M) ? t - (u32)(8 * M) : t; }
+    };
+    auto vote = [&](bool fail) -> bool {
+        if constexpr (W == 1) return __ballot(fail) != 0ull;
+        else {
+            if (threadIdx.x == 0) *flag = 0;
+            __syncthreads();
+            if (__ballot(fail) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+            __syncthreads();
+            const bool r = *flag != 0;
+            __syncthreads();
+            return r;
+        }
+    };
+    const double *const yrow = a.llr + fr * N + (valid ? n : 0);
+
+    double m1[RH], m2[RH];
+    u32 meta[RH];
+    static_for<0, RH>([&](auto J) { constexpr int j = decltype(J)::value; m1[j] = 0.0; m2[j] = 0.0; meta[j] = 0u; });
+
+    int res = -a.maxiter;
+    for (int iter = 0; iter < a.maxiter; ++iter) {
+        double y[NH];
+        int yo = 0;
+        asm volatile("" : "+v"(yo));
+        static_for<0, NH>([&](auto K) { constexpr int k = decltype(K)::value; y[k] = yrow[yo + k * M]; });
+        // ---------------- STATE1
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            u32 mt = meta[j], nb = n8;
+            asm volatile("" : "+v"(mt), "+v"(nb) :: "memory");  // compiler fence: this row's work stays behind the previous barrier
+            const u32 pos = mt >> 16;
+            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - C::RW[j]);
+            static_for<0, C::RW[j]>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                const double aa = sel64(m1[j], m2[j], lanes_eq(pos, (u32)s));
+                const double cv = signed_mag(aa, Wt);
+                Wt = twice(Wt);
+                double *p = reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M));
+                if (valid) {
+                    if constexpr (C::FIRST[j][s]) *p = cv;
+                    else __hip_atomic_fetch_add(p, cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            });
+            if constexpr (W > 1) __syncthreads();
+            else __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---------------- STATE2
+        if (valid) {
+            static_for<0, NH>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                double *p = reinterpret_cast<double *>(ldsb + n8 + k * (8 * M));
+                const double pr = *p * alpha;
+                *p = (y[k] + 0.0) + pr;
+                if constexpr (k % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        if constexpr (W > 1) __syncthreads();
+        // ---------------- STATE3
+        u32 failw = 0;
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int RW = C::RW[j];
+            u32 mt = meta[j];
+            asm volatile("" : "+v"(mt) :: "memory");
+            const u32 pos = mt >> 16;
+            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - RW);
+            double a1 = m1[j] * alpha, a2 = m2[j] * alpha;
+            asm volatile("" : "+v"(a1), "+v"(a2));
+            double nm1 = kMaxVal, nm2 = kMaxVal;
+            u32 npos = 0, nS = 0, sy = 0;
+            u32 nb = n8;
+            asm volatile("" : "+v"(nb));
+            double r[RW];
+            static_for<0, RW>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                r[s] = *reinterpret_cast<const double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M));
+            });
+            static_for<0, RW>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                sy ^= hi32(r[s]);
+                const double aa = sel64(a1, a2, lanes_eq(pos, (u32)s));
+                const double x = signed_mag(aa, Wt);
+                Wt = twice(Wt);
+                const double tt = r[s] - x;
+                nS = __builtin_amdgcn_alignbit(nS, hi32(tt), 31);
+                const double v = fabs(tt);
+                const mask64 c1 = lanes_lt(v, nm1);
+                nm2 = fmin(fmax(v, nm1), nm2);
+                npos = sel32(npos, (u32)s, c1);
+                nm1 = fmin(v, nm1);
+            });
+            failw |= sy;
+            m1[j] = nm1; m2[j] = nm2; meta[j] = nS | (npos << 16);
+            // materialise the new record HERE: it is only consumed by the next iteration, and without this the compiler
+            // sinks all 112 min1/min2 updates below the convergence branch and keeps every v2c alive across the vote
+            asm volatile("" : "+v"(m1[j]), "+v"(m2[j]), "+v"(meta[j]));
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (!vote(valid && (failw >> 31) != 0)) { res = iter + 1; break; }   // the vote's barriers also fence the next STATE1
+    }
+
+    if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
+    if (a.hard) {
+        constexpr int HW = (N + 31) / 32;
+        if constexpr (M % 64 == 0) {
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            static_for<0, NH>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                const u64 b = __ballot((*reinterpret_cast<const u32 *>(ldsb + n8 + k * (8 * M) + 4) >> 31) != 0);
+                if (lane == 0) reinterpret_cast<u64 *>(a.hard + fr * HW)[k * W + wave] = b;
+            });
+        } else {
+            for (int w = threadIdx.x; w < HW; w += W * 64) {
+                u32 bits = 0;
+                for (int b = 0; b < 32; ++b) {
+                    const int v = 32 * w + b;
+                    if (v < N) bits |= (*reinterpret_cast<const u32 *>(ldsb + (size_t)v * 8 + 4) >> 31) << b;
+                }
+                a.hard[fr * HW + w] = bits;
+            }
+        }
+    }
+    if (a.soft_out && valid) {
+        static_for<0, NH>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            a.soft_out[fr * N + k * M + n] = *reinterpret_cast<const double *>(ldsb + n8 + k * (8 * M));
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Layered offset min-sum (upstream lmin_sum_decod_qc_lm, decoders.cpp:5064-5425, active branch :5106-5290 with
 // MY_VERSION; semantics SURVEY Appendix A.3), code-specialised like the flooding kernel above, for any lifting
 // M <= 512: one frame per workgroup of W = ceil(M/64) wavefronts, a-posteriori values in LDS (8 B per variable,
