@@ -10,14 +10,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "ldpc_frontend.hpp"
 #include "ldpc_jit.hpp"
 #include "ldpc_kernels.hpp"
 #include "ldpc_ms_fast.hpp"
-#include "ldpc_ms_spec.hpp"
+#include "ldpc_spec.hpp"
 #include "code_appendix_c_m64.hpp"
 #include "ldpc_sumprod.hpp"
 
@@ -48,68 +50,124 @@ constexpr int kRWM = 16;   // max circulants per block row (edge-sign bits per r
 
 }  // namespace
 
-// ahead-of-time instance of the code-specialised kernel for the shipped example code
-__global__ void __launch_bounds__(64, 2) ms_spec_appendix_c_m64_kernel(const ldpc_spec::SpecArgs a) {
-    ldpc_spec::ms_m64_body<ldpc_spec::CodeAppendixCM64>(a);
-}
-
-__global__ void __launch_bounds__(128, 2) ms_spec_appendix_c_m126_kernel(const ldpc_spec::SpecArgs a) {
-    ldpc_spec::ms_body<ldpc_spec::CodeAppendixCM126>(a);
-}
-__global__ void __launch_bounds__(512, 2) ms_spec_appendix_c_m512_kernel(const ldpc_spec::SpecArgs a) {
-    ldpc_spec::ms_body<ldpc_spec::CodeAppendixCM512>(a);
-}
-__global__ void __launch_bounds__(64, 2) lms_spec_appendix_c_m64_kernel(const ldpc_spec::SpecArgs a) {
-    ldpc_spec::lms_body<ldpc_spec::CodeAppendixCM64>(a);
-}
-__global__ void __launch_bounds__(512, 2) lms_spec_appendix_c_m512_kernel(const ldpc_spec::SpecArgs a) {
-    ldpc_spec::lms_body<ldpc_spec::CodeAppendixCM512>(a);
-}
-
-__global__ void __launch_bounds__(512, 4) sp_spec_appendix_c_m64_kernel(const ldpc_spec::SpecArgs a) {
-    ldpc_spec::sp_body<ldpc_spec::CodeAppendixCM64>(a);
-}
-__global__ void __launch_bounds__(512, 2) sp_spec_appendix_c_m64_occ2_kernel(const ldpc_spec::SpecArgs a) {
-    ldpc_spec::sp_body<ldpc_spec::CodeAppendixCM64>(a);
-}
-
-__global__ void __launch_bounds__(64, 1) tasp_spec_appendix_c_m64_kernel(const ldpc_spec::SpecArgs a) {
-    ldpc_spec::tasp_body<ldpc_spec::CodeAppendixCM64>(a);
-}
-__global__ void __launch_bounds__(128, 1) tasp_spec_appendix_c_m126_kernel(const ldpc_spec::SpecArgs a) {
-    ldpc_spec::tasp_body<ldpc_spec::CodeAppendixCM126>(a);
-}
-
-template <class FC>
-static bool same_code(int rh, int nh, int M, const std::vector<int32_t> &row_start, const std::vector<uint32_t> &edges) {
-    bool same = rh == FC::RH && nh == FC::NH && M == FC::M;
-    for (int j = 0; same && j < rh; ++j) {
-        same = (row_start[j + 1] - row_start[j]) == FC::RW[j];
-        for (int e = row_start[j]; same && e < row_start[j + 1]; ++e)
-            same = (int)(edges[e] >> 16) == FC::COL[j][e - row_start[j]] && (int)(edges[e] & 0xffffu) == FC::SH[j][e - row_start[j]];
+// ---- code-specialised instances (ldpc_spec.hpp) ------------------------------------------------------------------
+// Ahead of time: the shipped example code at the liftings the BASELINE configurations use.
+// Everything else is compiled at ldpc_hip_open() with hiprtc from the same header (ldpc_jit.hpp).
+#define LDPC_AOT_KERNEL(name, body, Code, threads, waves_per_simd)                                   \
+    __global__ void __launch_bounds__(threads, waves_per_simd) name(const ldpc_spec::SpecArgs a) {   \
+        ldpc_spec::body<ldpc_spec::Code>(a);                                                         \
     }
-    return same;
-}
+LDPC_AOT_KERNEL(ms_spec_appendix_c_m64_kernel, ms_m64_body, CodeAppendixCM64, 64, 2)
+LDPC_AOT_KERNEL(ms_spec_appendix_c_m126_kernel, ms_body, CodeAppendixCM126, 128, 2)
+LDPC_AOT_KERNEL(ms_spec_appendix_c_m512_kernel, ms_body, CodeAppendixCM512, 512, 2)
+LDPC_AOT_KERNEL(lms_spec_appendix_c_m64_kernel, lms_body, CodeAppendixCM64, 64, 2)
+LDPC_AOT_KERNEL(lms_spec_appendix_c_m512_kernel, lms_body, CodeAppendixCM512, 512, 2)
+// two frames per CU (<= 128 VGPRs, a few spills) beats one frame with 243 VGPRs: 4.18 vs 3.70 M frames/s at 2 dB
+LDPC_AOT_KERNEL(sp_spec_appendix_c_m64_kernel, sp_body, CodeAppendixCM64, 512, 4)
+LDPC_AOT_KERNEL(tasp_spec_appendix_c_m64_kernel, tasp_body, CodeAppendixCM64, 64, 1)
+LDPC_AOT_KERNEL(tasp_spec_appendix_c_m126_kernel, tasp_body, CodeAppendixCM126, 128, 1)
+
+namespace {
+
+// the opened base matrix as edge lists (row-major = upstream's j-then-k loop order)
+struct CodeTables {
+    int rh = 0, nh = 0, M = 0, ne = 0, max_rw = 0, min_rw = 1 << 30, max_cw = 0;
+    bool all_cols_used = true;
+    std::vector<int32_t> row_start, col_start;
+    std::vector<uint32_t> edges;      // (block column << 16) | shift
+    std::vector<uint32_t> col_edges;  // (block row << 16) | shift, column-major
+    std::vector<uint32_t> col_slot;   // row-major edge id of the column-major entries
+    std::vector<uint32_t> edge_row;   // block row of each row-major edge
+
+    CodeTables(int rh_, int nh_, int M_, const int16_t *hd) : rh(rh_), nh(nh_), M(M_), row_start(rh_ + 1), col_start(nh_ + 1) {
+        for (int j = 0; j < rh; ++j) {
+            row_start[j] = (int32_t)edges.size();
+            for (int k = 0; k < nh; ++k) {
+                int v = hd[j * nh + k];
+                if (v == -1) continue;
+                while (v < 0) v += M;   // rotate() reduces the shift like this (decoders.cpp:335-339)
+                while (v >= M) v -= M;
+                edges.push_back(((uint32_t)k << 16) | (uint32_t)v);
+                edge_row.push_back((uint32_t)j);
+            }
+            const int rw = (int)edges.size() - row_start[j];
+            max_rw = rw > max_rw ? rw : max_rw;
+            min_rw = rw < min_rw ? rw : min_rw;
+        }
+        row_start[rh] = (int32_t)edges.size();
+        ne = (int)edges.size();
+        for (int k = 0; k < nh; ++k) {
+            col_start[k] = (int32_t)col_edges.size();
+            for (int e = 0; e < ne; ++e)
+                if ((int)(edges[e] >> 16) == k) {     // row-major order == rows ascending inside a column
+                    col_edges.push_back((edge_row[e] << 16) | (edges[e] & 0xffffu));
+                    col_slot.push_back((uint32_t)e);
+                }
+            const int cw = (int)col_edges.size() - col_start[k];
+            max_cw = cw > max_cw ? cw : max_cw;
+            all_cols_used = all_cols_used && cw > 0;
+        }
+        col_start[nh] = (int32_t)col_edges.size();
+    }
+    std::vector<std::vector<std::pair<int, int>>> rows() const {
+        std::vector<std::vector<std::pair<int, int>>> r(rh);
+        for (int e = 0; e < ne; ++e) r[edge_row[e]].emplace_back((int)(edges[e] >> 16), (int)(edges[e] & 0xffffu));
+        return r;
+    }
+    template <class FC>
+    bool is() const {  // does the opened matrix equal the constexpr tables FC?
+        bool same = rh == FC::RH && nh == FC::NH && M == FC::M;
+        for (int j = 0; same && j < rh; ++j) {
+            same = (row_start[j + 1] - row_start[j]) == FC::RW[j];
+            for (int e = row_start[j]; same && e < row_start[j + 1]; ++e)
+                same = (int)(edges[e] >> 16) == FC::COL[j][e - row_start[j]] && (int)(edges[e] & 0xffffu) == FC::SH[j][e - row_start[j]];
+        }
+        return same;
+    }
+};
+
+struct AotInstance {
+    int decoder;
+    const void *fn;
+    int threads;
+    const char *name;
+    bool (CodeTables::*matches)() const;
+};
+const AotInstance kAot[] = {
+    {LDPC_HIP_MS_DEC, (const void *)ms_spec_appendix_c_m64_kernel, 64, "ms_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
+    {LDPC_HIP_MS_DEC, (const void *)ms_spec_appendix_c_m126_kernel, 128, "ms_spec_appendix_c_m126_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM126>},
+    {LDPC_HIP_MS_DEC, (const void *)ms_spec_appendix_c_m512_kernel, 512, "ms_spec_appendix_c_m512_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM512>},
+    {LDPC_HIP_LMS_DEC, (const void *)lms_spec_appendix_c_m64_kernel, 64, "lms_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
+    {LDPC_HIP_LMS_DEC, (const void *)lms_spec_appendix_c_m512_kernel, 512, "lms_spec_appendix_c_m512_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM512>},
+    {LDPC_HIP_SP_DEC, (const void *)sp_spec_appendix_c_m64_kernel, 512, "sp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
+    {LDPC_HIP_TASP_DEC, (const void *)tasp_spec_appendix_c_m64_kernel, 64, "tasp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
+    {LDPC_HIP_TASP_DEC, (const void *)tasp_spec_appendix_c_m126_kernel, 128, "tasp_spec_appendix_c_m126_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM126>},
+};
+
+}  // namespace
 
 struct ldpc_hip_ctx {
     int decoder_id = 0, device = 0;
     int rh = 0, nh = 0, M = 0, N = 0, R = 0, ne = 0, hard_words = 0;
-    int max_rw = 0, max_cw = 0;
-    int F = 1;        // frames per workgroup (M <= 64: floor(64/M))
-    int threads = 64; // workgroup size of the decode kernel
+    // generic (table-driven) kernel geometry
+    int F = 1;         // frames per workgroup (M <= 64: floor(64/M))
+    int threads = 64;  // workgroup size
     bool multiwave = false;
     size_t lds_bytes = 0;
-    double ims_thr = 1.4;      // MS_THR, MS_QBITS, MS_DBITS (decoders.h:46-48), see ldpc_hip_set_ims_params
+    double ims_thr = 1.4;  // MS_THR, MS_QBITS, MS_DBITS (decoders.h:46-48), see ldpc_hip_set_ims_params
     int ims_qbits = 6, ims_dbits = 8;
-    bool fast_m64 = false;     // flagship path: min-sum, M == 64, table in the kernel-argument segment
-    int fast_variant = 2;      // LDPC_HIP_MS_VARIANT: 2 = code-specialised (AOT/JIT) [default], 0 = table kernel with LDS
-                               // fp64 atomics, 1 = table kernel read-add-write, -1 = generic kernel
-    bool spec_aot = false;     // the opened matrix is the shipped example code: use the ahead-of-time instance
-    int spec_threads = 64;     // workgroup size of the code-specialised kernel (one frame per workgroup)
-    const ldpc_jit::Kernel *jit = nullptr;  // code-specialised instance compiled at open() for any other matrix
-    std::string kernel_name;   // which decode kernel this context launches (ldpc_hip_kernel_name)
+    // table-driven M = 64 min-sum kernel (ldpc_ms_fast.hpp)
+    bool fast_m64 = false;
+    int variant = 2;  // LDPC_HIP_MS_VARIANT: 2 code-specialised (AOT / hiprtc) [default], 0 table kernel with LDS fp64 atomics,
+                      // 1 table kernel read-add-write, -1 generic kernels only
     ldpc::FastTab fast_tab;
-    // device tables
+    // code-specialised kernel (ldpc_spec.hpp): one frame per workgroup of spec_threads threads
+    const void *spec_aot = nullptr;
+    const ldpc_jit::Kernel *spec_jit = nullptr;
+    int spec_threads = 64;
+    size_t spec_lds = 0;
+    std::string kernel_name;  // what this context launches (ldpc_hip_kernel_name)
+    // device tables of the generic kernels
     int32_t *d_row_start = nullptr, *d_col_start = nullptr;
     uint32_t *d_edges = nullptr, *d_col_edges = nullptr, *d_col_slot = nullptr, *d_edge_row = nullptr;
     // workspace for ldpc_hip_simulate / decode_host
@@ -156,13 +214,39 @@ int ensure_workspace(ldpc_hip_ctx *c, long long B, bool need_soft) {
     return 0;
 }
 
-template <typename K>
-int set_lds_limit(K kernel, size_t bytes) {
-    if (bytes > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)bytes));
-    }
+int set_lds_limit(const void *kernel, size_t bytes) {
+    if (bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
+}
+
+// Which code-specialised body serves this decoder / code shape, if any.  `required`: no generic kernel exists.
+struct SpecPlan { const char *body = nullptr; int threads = 0; size_t lds = 0; bool required = false; };
+
+SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
+    SpecPlan p;
+    const int M = t.M, N = t.nh * t.M, W = (M + 63) / 64;
+    const size_t soft_lds = sizeof(double) * (size_t)N + 16;  // a-posteriori values + vote flag
+    if (!t.all_cols_used || t.max_rw > 16 || t.rh > 64 || t.nh > 64) return p;
+    switch (decoder_id) {
+    case LDPC_HIP_MS_DEC:
+        if (M == 64) { p.body = "ms_m64_body"; p.threads = 64; p.lds = sizeof(double) * (size_t)N; }
+        else if (M >= 48 && M <= 512 && soft_lds <= 160 * 1024) { p.body = "ms_body"; p.threads = 64 * W; p.lds = soft_lds; }
+        break;
+    case LDPC_HIP_LMS_DEC:
+        if (M >= 48 && M <= 512 && soft_lds <= 160 * 1024) { p.body = "lms_body"; p.threads = 64 * W; p.lds = soft_lds; }
+        break;
+    case LDPC_HIP_SP_DEC: {
+        const size_t lds = ldpc::sp_lds_bytes(t.ne, M, t.rh * M, N);
+        if (M % 64 == 0 && lds <= 160 * 1024) { p.body = "sp_body"; p.threads = 512; p.lds = lds; }
+        break;
+    }
+    case LDPC_HIP_TASP_DEC:
+        p.required = true;  // per-edge state lives in VGPRs of the check lane: code-specialised instances only
+        if (M <= 256 && t.min_rw >= 2 && t.ne <= 144 && soft_lds <= 64 * 1024) { p.body = "tasp_body"; p.threads = 64 * W; p.lds = soft_lds; }
+        break;
+    default: break;
+    }
+    return p;
 }
 
 }  // namespace
@@ -185,232 +269,96 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
     if (decoder_id != LDPC_HIP_MS_DEC && decoder_id != LDPC_HIP_LMS_DEC && decoder_id != LDPC_HIP_SP_DEC && decoder_id != LDPC_HIP_IMS_DEC &&
         decoder_id != LDPC_HIP_TASP_DEC)
         return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_open: decoder id %d is not built (built: SP=1, MS=3, IMS=4, TASP=7, LMS=8)", decoder_id);
+    if (M >= 65536 || nh >= 65536) return fail(LDPC_HIP_EUNSUPPORTED, "M and nh must be < 65536");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(LDPC_HIP_EINVAL, "ldpc_hip_open: device %d of %d", device, ndev);
 
-    ldpc_hip_ctx *c = new ldpc_hip_ctx();
+    const CodeTables t(rh, nh, M, hd);
+    std::unique_ptr<ldpc_hip_ctx, void (*)(ldpc_hip_ctx *)> c(new ldpc_hip_ctx(), ldpc_hip_close);
     c->decoder_id = decoder_id; c->device = device;
-    c->rh = rh; c->nh = nh; c->M = M; c->N = nh * M; c->R = rh * M;
+    c->rh = rh; c->nh = nh; c->M = M; c->N = nh * M; c->R = rh * M; c->ne = t.ne;
     c->hard_words = (c->N + 31) / 32;
+    const char *venv = getenv("LDPC_HIP_MS_VARIANT");
+    c->variant = venv ? atoi(venv) : 2;
 
-    std::vector<int32_t> row_start(rh + 1), col_start(nh + 1);
-    std::vector<uint32_t> edges, col_edges, col_slot;
-    std::vector<int> slot_of;  // per row-major edge: index inside its row
-    for (int j = 0; j < rh; ++j) {
-        row_start[j] = (int32_t)edges.size();
-        for (int k = 0; k < nh; ++k) {
-            int v = hd[j * nh + k];
-            if (v == -1) continue;
-            while (v < 0) v += M;   // rotate() reduces the shift like this (decoders.cpp:335-339)
-            while (v >= M) v -= M;
-            slot_of.push_back((int)edges.size() - row_start[j]);
-            edges.push_back(((uint32_t)k << 16) | (uint32_t)v);
-        }
-        const int rw = (int)edges.size() - row_start[j];
-        if (rw > c->max_rw) c->max_rw = rw;
-    }
-    row_start[rh] = (int32_t)edges.size();
-    c->ne = (int)edges.size();
-    for (int k = 0; k < nh; ++k) {
-        col_start[k] = (int32_t)col_edges.size();
-        for (int j = 0; j < rh; ++j)
-            for (int e = row_start[j]; e < row_start[j + 1]; ++e)
-                if ((int)(edges[e] >> 16) == k) {
-                    col_edges.push_back(((uint32_t)j << 16) | (edges[e] & 0xffffu));
-                    col_slot.push_back((uint32_t)e);  // global edge id (row-major)
-                }
-        const int cw = (int)col_edges.size() - col_start[k];
-        if (cw > c->max_cw) c->max_cw = cw;
-    }
-    col_start[nh] = (int32_t)col_edges.size();
-
-    // what the kernels were instantiated for
-    if (M >= 65536 || nh >= 65536) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "M and nh must be < 65536"); }
-    if (decoder_id == LDPC_HIP_TASP_DEC) {
-        // TDMP sum-product exists as code-specialised instances only (per-edge state in VGPRs of the check lane)
-        int min_rw = 1 << 30, regs = 0;
-        for (int j = 0; j < rh; ++j) { const int rw = row_start[j + 1] - row_start[j]; min_rw = rw < min_rw ? rw : min_rw; regs += 2 * rw; }
-        if (M > 256 || min_rw < 2 || regs > 288 || sizeof(double) * (size_t)c->N + 16 > 64 * 1024) {
-            delete c;
-            return fail(LDPC_HIP_EUNSUPPORTED, "TASP: needs M <= 256 (got %d), every block row of weight >= 2 (min %d), <= 144 circulants (got %d) and "
-                        "N <= 8190 (got %d)", M, min_rw, regs / 2, nh * M);
-        }
-        c->F = 1; c->multiwave = M > 64;
-        c->spec_threads = c->threads = ((M + 63) / 64) * 64;
-        c->lds_bytes = sizeof(double) * (size_t)c->N + 16;
-        if (same_code<ldpc_spec::CodeAppendixCM64>(rh, nh, M, row_start, edges) ||
-            same_code<ldpc_spec::CodeAppendixCM126>(rh, nh, M, row_start, edges)) {
-            c->spec_aot = true;
-            c->kernel_name = M == 64 ? "tasp_spec_appendix_c_m64_kernel (ahead of time)" : "tasp_spec_appendix_c_m126_kernel (ahead of time)";
-        } else {
-            std::vector<std::vector<std::pair<int, int>>> rows(rh);
-            for (int j = 0; j < rh; ++j)
-                for (int e2 = row_start[j]; e2 < row_start[j + 1]; ++e2)
-                    rows[j].emplace_back((int)(edges[e2] >> 16), (int)(edges[e2] & 0xffffu));
-            std::string jerr;
-            c->jit = ldpc_jit::get(device, "tasp_body", rows, nh, M, jerr);
-            if (!c->jit) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "TASP needs a hiprtc instance for this base matrix: %s", jerr.c_str()); }
-            c->kernel_name = "tasp_spec_jit (hiprtc)";
-        }
-    } else if (decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || decoder_id == LDPC_HIP_IMS_DEC) {
-        if (rh > kRHM) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "rh=%d > %d block rows", rh, kRHM); }
-        if (c->max_rw > kRWM) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "row weight %d > %d", c->max_rw, kRWM); }
-        if ((decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_IMS_DEC) && nh > kNHM) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "nh=%d > %d block columns", nh, kNHM); }
-        if (M > 512) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "M=%d > 512", M); }
+    // ---- generic (table-driven) kernel for this decoder, where one exists
+    bool have_generic = false;
+    if (decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || decoder_id == LDPC_HIP_IMS_DEC) {
+        const bool needs_nh = decoder_id != LDPC_HIP_LMS_DEC;  // the flooding kernels keep the channel LLRs of kNHM block columns in VGPRs
         c->multiwave = M > 64;
         c->F = c->multiwave ? 1 : 64 / M;
         c->threads = c->multiwave ? ((M + 63) / 64) * 64 : 64;
         c->lds_bytes = sizeof(double) * (size_t)c->N * c->F + 16;
-        bool all_cols_used = true;
-        for (int k = 0; k < nh; ++k) all_cols_used = all_cols_used && (col_start[k + 1] > col_start[k]);
-        const char *venv = getenv("LDPC_HIP_MS_VARIANT");
-        c->fast_variant = venv ? atoi(venv) : 2;
-        c->kernel_name = decoder_id == LDPC_HIP_MS_DEC ? (c->multiwave ? "ms_flood_kernel<multiwave>" : "ms_flood_kernel")
-                       : decoder_id == LDPC_HIP_IMS_DEC ? (c->multiwave ? "ims_flood_kernel<multiwave>" : "ims_flood_kernel")
-                                                        : (c->multiwave ? "lms_layered_kernel<multiwave>" : "lms_layered_kernel");
-        const bool m64 = decoder_id == LDPC_HIP_MS_DEC && M == 64 && rh <= ldpc::kFastRows && nh <= ldpc::kFastCols && all_cols_used;
-        if (m64 && c->max_rw <= ldpc::kFastSlots && c->fast_variant >= 0) {
-            // table-driven M = 64 kernel (always available)
+        have_generic = rh <= kRHM && t.max_rw <= kRWM && (!needs_nh || nh <= kNHM) && M <= 512 && c->lds_bytes <= 160 * 1024;
+        const char *base = decoder_id == LDPC_HIP_MS_DEC ? "ms_flood_kernel" : decoder_id == LDPC_HIP_IMS_DEC ? "ims_flood_kernel" : "lms_layered_kernel";
+        c->kernel_name = std::string(base) + (c->multiwave ? "<multiwave>" : "");
+        if (have_generic && decoder_id == LDPC_HIP_MS_DEC && M == 64 && rh <= ldpc::kFastRows && nh <= ldpc::kFastCols && t.all_cols_used &&
+            t.max_rw <= ldpc::kFastSlots && c->variant >= 0) {
+            // table-driven M = 64 kernel: 64 dwords of packed descriptors that stay in SGPRs
             c->fast_m64 = true;
-            c->kernel_name = c->fast_variant == 1 ? "ms_flood_m64_kernel<rmw>" : "ms_flood_m64_kernel<atomic>";
+            c->kernel_name = c->variant == 1 ? "ms_flood_m64_kernel<rmw>" : "ms_flood_m64_kernel<atomic>";
             std::memset(&c->fast_tab, 0, sizeof c->fast_tab);
             std::vector<char> seen(nh, 0);
-            for (int j = 0; j < rh; ++j)
-                for (int e = row_start[j]; e < row_start[j + 1]; ++e) {
-                    const uint32_t k = edges[e] >> 16, sh = edges[e] & 0xffffu;
-                    const uint32_t first = seen[k] ? 0u : 1u;  // rows ascend: the first hit is the column's first edge
-                    seen[k] = 1;
-                    const int slot = e - row_start[j];
-                    c->fast_tab.pk[j][slot >> 1] |= ldpc::fast_desc(first, k, sh) << ((slot & 1) * 16);
-                }
+            for (int e = 0; e < t.ne; ++e) {
+                const uint32_t j = t.edge_row[e], k = t.edges[e] >> 16, sh = t.edges[e] & 0xffffu;
+                const uint32_t first = seen[k] ? 0u : 1u;  // rows ascend: the first hit is the column's first edge
+                seen[k] = 1;
+                const int slot = e - t.row_start[j];
+                c->fast_tab.pk[j][slot >> 1] |= ldpc::fast_desc(first, k, sh) << ((slot & 1) * 16);
+            }
             c->lds_bytes = sizeof(double) * 2048;
         }
-        if (m64 && c->max_rw <= 16 && c->fast_variant == 2) {
-            // code-specialised kernel: ahead-of-time instance for the shipped example code, hiprtc for anything else
-            const bool same = same_code<ldpc_spec::CodeAppendixCM64>(rh, nh, M, row_start, edges);
-            const char *jenv = getenv("LDPC_HIP_JIT");
-            if (same) {
-                c->spec_aot = true;
-                c->kernel_name = "ms_spec_appendix_c_m64_kernel (ahead of time)";
-                c->lds_bytes = sizeof(double) * (size_t)c->N;
-            } else if (!jenv || atoi(jenv) != 0) {
-                std::vector<std::vector<std::pair<int, int>>> rows(rh);
-                for (int j = 0; j < rh; ++j)
-                    for (int e = row_start[j]; e < row_start[j + 1]; ++e)
-                        rows[j].emplace_back((int)(edges[e] >> 16), (int)(edges[e] & 0xffffu));
-                std::string jerr;
-                c->jit = ldpc_jit::get(device, "ms_m64_body", rows, nh, M, jerr);
-                if (c->jit) {
-                    c->kernel_name = "ms_spec_jit (hiprtc)";
-                    c->lds_bytes = sizeof(double) * (size_t)c->N;
-                } else {
-                    fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", jerr.c_str(),
-                            c->kernel_name.c_str());
-                }
-            }
-        }
-        if (decoder_id == LDPC_HIP_MS_DEC && M != 64 && M >= 48 && all_cols_used && c->fast_variant == 2 && nh <= 64 && c->max_rw <= 16 &&
-            sizeof(double) * (size_t)c->N + 16 <= 160 * 1024) {
-            // code-specialised flooding min-sum for liftings other than 64: one frame per workgroup of ceil(M/64) waves
-            const char *jenv = getenv("LDPC_HIP_JIT");
-            c->spec_threads = ((M + 63) / 64) * 64;
-            if (same_code<ldpc_spec::CodeAppendixCM126>(rh, nh, M, row_start, edges) ||
-                same_code<ldpc_spec::CodeAppendixCM512>(rh, nh, M, row_start, edges)) {
-                c->spec_aot = true;
-                c->kernel_name = M == 126 ? "ms_spec_appendix_c_m126_kernel (ahead of time)" : "ms_spec_appendix_c_m512_kernel (ahead of time)";
-            } else if (!jenv || atoi(jenv) != 0) {
-                std::vector<std::vector<std::pair<int, int>>> rows(rh);
-                for (int j = 0; j < rh; ++j)
-                    for (int e = row_start[j]; e < row_start[j + 1]; ++e)
-                        rows[j].emplace_back((int)(edges[e] >> 16), (int)(edges[e] & 0xffffu));
-                std::string jerr;
-                c->jit = ldpc_jit::get(device, "ms_body", rows, nh, M, jerr);
-                if (c->jit) c->kernel_name = "ms_spec_jit (hiprtc, multi-wave)";
-                else fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", jerr.c_str(), c->kernel_name.c_str());
-            }
-            if (c->spec_aot || c->jit) c->lds_bytes = sizeof(double) * (size_t)c->N + 16;
-        }
-        if (decoder_id == LDPC_HIP_LMS_DEC && M >= 48 && all_cols_used && c->fast_variant == 2 &&
-            sizeof(double) * (size_t)c->N + 16 <= 160 * 1024) {
-            // code-specialised layered min-sum: one frame per workgroup of ceil(M/64) waves
-            const char *jenv = getenv("LDPC_HIP_JIT");
-            c->spec_threads = ((M + 63) / 64) * 64;
-            if (same_code<ldpc_spec::CodeAppendixCM64>(rh, nh, M, row_start, edges) ||
-                same_code<ldpc_spec::CodeAppendixCM512>(rh, nh, M, row_start, edges)) {
-                c->spec_aot = true;
-                c->kernel_name = M == 64 ? "lms_spec_appendix_c_m64_kernel (ahead of time)" : "lms_spec_appendix_c_m512_kernel (ahead of time)";
-            } else if (!jenv || atoi(jenv) != 0) {
-                std::vector<std::vector<std::pair<int, int>>> rows(rh);
-                for (int j = 0; j < rh; ++j)
-                    for (int e = row_start[j]; e < row_start[j + 1]; ++e)
-                        rows[j].emplace_back((int)(edges[e] >> 16), (int)(edges[e] & 0xffffu));
-                std::string jerr;
-                c->jit = ldpc_jit::get(device, "lms_body", rows, nh, M, jerr);
-                if (c->jit) c->kernel_name = "lms_spec_jit (hiprtc)";
-                else fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", jerr.c_str(), c->kernel_name.c_str());
-            }
-            if (c->spec_aot || c->jit) c->lds_bytes = sizeof(double) * (size_t)c->N + 16;
-        }
-    } else {
-        c->multiwave = true;
-        c->F = 1;
-        c->threads = ldpc::kSpThreads;
-        c->lds_bytes = ldpc::sp_lds_bytes(c->ne, M, c->R, c->N);
+    } else if (decoder_id == LDPC_HIP_SP_DEC) {
+        c->multiwave = true; c->F = 1; c->threads = ldpc::kSpThreads;
+        c->lds_bytes = ldpc::sp_lds_bytes(t.ne, M, c->R, c->N);
         c->kernel_name = "sp_flood_kernel";
-        if (c->N > ldpc::kSpNVM * c->threads) { delete c; return fail(LDPC_HIP_EUNSUPPORTED, "sum-product: N=%d > %d", c->N, ldpc::kSpNVM * c->threads); }
-        {   // code-specialised sum-product: liftings that are a multiple of 64 and fit the LDS
-            const char *venv = getenv("LDPC_HIP_MS_VARIANT");
-            c->fast_variant = venv ? atoi(venv) : 2;
-            const char *jenv = getenv("LDPC_HIP_JIT");
-            bool all_cols_used = true;
-            for (int k = 0; k < nh; ++k) all_cols_used = all_cols_used && (col_start[k + 1] > col_start[k]);
-            if (c->fast_variant >= 2 && M % 64 == 0 && all_cols_used && rh <= 64 && c->lds_bytes <= 160 * 1024) {
-                c->spec_threads = 512;
-                if (same_code<ldpc_spec::CodeAppendixCM64>(rh, nh, M, row_start, edges)) {
-                    c->spec_aot = true;
-                    // two frames per CU (<= 128 VGPRs, a few spills) beats one frame with 243 VGPRs: 4.18 vs 3.70 M frames/s at 2 dB
-                    c->kernel_name = c->fast_variant == 3 ? "sp_spec_appendix_c_m64_occ2_kernel (ahead of time)" : "sp_spec_appendix_c_m64_kernel (ahead of time)";
-                } else if (!jenv || atoi(jenv) != 0) {
-                    std::vector<std::vector<std::pair<int, int>>> rows(rh);
-                    for (int j = 0; j < rh; ++j)
-                        for (int e2 = row_start[j]; e2 < row_start[j + 1]; ++e2)
-                            rows[j].emplace_back((int)(edges[e2] >> 16), (int)(edges[e2] & 0xffffu));
-                    std::string jerr;
-                    c->jit = ldpc_jit::get(device, "sp_body", rows, nh, M, jerr);
-                    if (c->jit) c->kernel_name = "sp_spec_jit (hiprtc)";
-                    else fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", jerr.c_str(), c->kernel_name.c_str());
-                }
-            }
-        }
-    }
-    if (c->lds_bytes > 160 * 1024) {
-        const size_t need = c->lds_bytes;
-        delete c;
-        return fail(LDPC_HIP_EUNSUPPORTED, "code needs %zu B of LDS per workgroup (> 160 KiB)", need);
+        have_generic = c->N <= ldpc::kSpNVM * c->threads && c->lds_bytes <= 160 * 1024;
     }
 
-    hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipMalloc(&c->d_row_start, sizeof(int32_t) * (rh + 1));
-    if (e == hipSuccess) e = hipMalloc(&c->d_col_start, sizeof(int32_t) * (nh + 1));
-    if (e == hipSuccess) e = hipMalloc(&c->d_edges, sizeof(uint32_t) * (c->ne + 1));
-    if (e == hipSuccess) e = hipMalloc(&c->d_col_edges, sizeof(uint32_t) * (c->ne + 1));
-    if (e == hipSuccess) e = hipMalloc(&c->d_col_slot, sizeof(uint32_t) * (c->ne + 1));
-    if (e == hipSuccess) e = hipMalloc(&c->d_edge_row, sizeof(uint32_t) * (c->ne + 1));
-    std::vector<uint32_t> edge_row(c->ne + 1, 0);
-    for (int j = 0; j < rh; ++j) for (int q = row_start[j]; q < row_start[j + 1]; ++q) edge_row[q] = (uint32_t)j;
-    if (e == hipSuccess && c->ne) e = hipMemcpy(c->d_edge_row, edge_row.data(), sizeof(uint32_t) * c->ne, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&c->w_counters, sizeof(unsigned long long) * 8);
-    if (e == hipSuccess) e = hipMemcpy(c->d_row_start, row_start.data(), sizeof(int32_t) * (rh + 1), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(c->d_col_start, col_start.data(), sizeof(int32_t) * (nh + 1), hipMemcpyHostToDevice);
-    if (e == hipSuccess && c->ne) e = hipMemcpy(c->d_edges, edges.data(), sizeof(uint32_t) * c->ne, hipMemcpyHostToDevice);
-    if (e == hipSuccess && c->ne) e = hipMemcpy(c->d_col_edges, col_edges.data(), sizeof(uint32_t) * c->ne, hipMemcpyHostToDevice);
-    if (e == hipSuccess && c->ne) e = hipMemcpy(c->d_col_slot, col_slot.data(), sizeof(uint32_t) * c->ne, hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        ldpc_hip_close(c);
-        return fail(LDPC_HIP_EHIP, "ldpc_hip_open: %s", hipGetErrorString(e));
+    // ---- code-specialised instance: ahead of time for the shipped example code, hiprtc for anything else
+    const SpecPlan plan = plan_spec(decoder_id, t);
+    std::string why_not = plan.body ? "" : "this code shape has no code-specialised kernel";
+    if (plan.body && (c->variant >= 2 || plan.required)) {
+        c->spec_threads = plan.threads; c->spec_lds = plan.lds;
+        for (const AotInstance &inst : kAot)
+            if (inst.decoder == decoder_id && inst.threads == plan.threads && (t.*inst.matches)()) {
+                c->spec_aot = inst.fn;
+                c->kernel_name = std::string(inst.name) + " (ahead of time)";
+                break;
+            }
+        const char *jenv = getenv("LDPC_HIP_JIT");
+        if (!c->spec_aot && (!jenv || atoi(jenv) != 0)) {
+            c->spec_jit = ldpc_jit::get(device, plan.body, t.rows(), nh, M, why_not);
+            if (c->spec_jit) c->kernel_name = std::string(plan.body) + " instance (hiprtc)";
+        } else if (!c->spec_aot) {
+            why_not = "LDPC_HIP_JIT=0";
+        }
     }
-    *out = c;
+    if (!c->spec_aot && !c->spec_jit) {
+        if (!have_generic)
+            return fail(LDPC_HIP_EUNSUPPORTED, "decoder %d, code %dx%d lifting %d: not supported by the generic kernel (limits: %d block rows, "
+                        "%d block columns, row weight %d, M <= 512, 160 KiB LDS) and no code-specialised instance: %s",
+                        decoder_id, rh, nh, M, kRHM, kNHM, kRWM, why_not.c_str());
+        if (plan.body && c->variant >= 2)
+            fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", why_not.c_str(), c->kernel_name.c_str());
+    }
+
+    HIP_TRY(hipSetDevice(device));
+    auto upload = [&](auto **dst, const auto &src) -> hipError_t {
+        using T = typename std::remove_reference<decltype(src)>::type::value_type;
+        hipError_t e = hipMalloc(dst, sizeof(T) * (src.size() + 1));
+        if (e == hipSuccess && !src.empty()) e = hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice);
+        return e;
+    };
+    HIP_TRY(upload(&c->d_row_start, t.row_start));
+    HIP_TRY(upload(&c->d_col_start, t.col_start));
+    HIP_TRY(upload(&c->d_edges, t.edges));
+    HIP_TRY(upload(&c->d_col_edges, t.col_edges));
+    HIP_TRY(upload(&c->d_col_slot, t.col_slot));
+    HIP_TRY(upload(&c->d_edge_row, t.edge_row));
+    HIP_TRY(hipMalloc(&c->w_counters, sizeof(unsigned long long) * 8));
+    *out = c.release();
     return 0;
 }
 
@@ -440,20 +388,9 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
     if (!c || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_decode_dev: bad argument");
     if (B == 0) return 0;  // empty batch: nothing to do (an empty device tensor has a null pointer)
     if (!d_llr) return fail(LDPC_HIP_EINVAL, "ldpc_hip_decode_dev: null llr");
+    if (B > 0x7fffffffLL) return fail(LDPC_HIP_EINVAL, "batch too large");
     if (int rc = set_device(c)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-
-    ldpc::DecArgs a{};
-    a.llr = d_llr; a.hard = d_hard; a.iters = d_iters; a.soft_out = d_soft;
-    a.row_start = c->d_row_start; a.edges = c->d_edges;
-    a.col_start = c->d_col_start; a.col_edges = c->d_col_edges; a.col_slot = c->d_col_slot; a.edge_row = c->d_edge_row;
-    a.B = B; a.rh = c->rh; a.nh = c->nh; a.M = c->M; a.N = c->N; a.F = c->F;
-    a.maxiter = maxiter; a.hard_words = c->hard_words; a.alpha = alpha;
-    a.ims_thr = c->ims_thr; a.ims_qbits = c->ims_qbits; a.ims_dbits = c->ims_dbits;
-
-    const long long blocks = (B + c->F - 1) / c->F;
-    if (blocks > 0x7fffffffLL) return fail(LDPC_HIP_EINVAL, "batch too large");
-    const dim3 grid((unsigned)blocks), block((unsigned)c->threads);
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->prof) {
@@ -461,108 +398,56 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
         HIP_TRY(hipEventCreate(&ev1));
         HIP_TRY(hipEventRecord(ev0, stream));
     }
-    switch (c->decoder_id) {
-    case LDPC_HIP_MS_DEC:
-        if (c->spec_aot || c->jit) {
-            ldpc_spec::SpecArgs sa{};
-            sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
-            if (c->spec_aot && c->M == 64) {
-                hipLaunchKernelGGL(ms_spec_appendix_c_m64_kernel, dim3((unsigned)B), dim3(64), c->lds_bytes, stream, sa);
-            } else if (c->spec_aot && c->M == 126) {
-                hipLaunchKernelGGL(ms_spec_appendix_c_m126_kernel, dim3((unsigned)B), dim3(128), c->lds_bytes, stream, sa);
-            } else if (c->spec_aot) {
-                if (int rc = set_lds_limit(ms_spec_appendix_c_m512_kernel, c->lds_bytes)) return rc;
-                hipLaunchKernelGGL(ms_spec_appendix_c_m512_kernel, dim3((unsigned)B), dim3(512), c->lds_bytes, stream, sa);
-            } else {
-                void *kargs[] = {&sa};
-                HIP_TRY(hipModuleLaunchKernel(c->jit->fn, (unsigned)B, 1, 1, (unsigned)c->spec_threads, 1, 1, (unsigned)c->lds_bytes, stream,
-                                              kargs, nullptr));
-            }
-        } else if (c->fast_m64) {
-            if (c->fast_variant == 1) hipLaunchKernelGGL(ldpc::ms_flood_m64_kernel<false>, grid, block, c->lds_bytes, stream, a, c->fast_tab);
-            else hipLaunchKernelGGL(ldpc::ms_flood_m64_kernel<true>, grid, block, c->lds_bytes, stream, a, c->fast_tab);
-        } else if (c->multiwave) {
-            auto k = ldpc::ms_flood_kernel<kRHM, kNHM, true>;
-            if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
-            hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
-        } else {
-            auto k = ldpc::ms_flood_kernel<kRHM, kNHM, false>;
-            if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
-            hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
-        }
-        break;
-    case LDPC_HIP_LMS_DEC:
-        if (c->spec_aot || c->jit) {
-            ldpc_spec::SpecArgs sa{};
-            sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
-            if (B > 0x7fffffffLL) return fail(LDPC_HIP_EINVAL, "batch too large");
-            if (c->spec_aot && c->M == 64) {
-                hipLaunchKernelGGL(lms_spec_appendix_c_m64_kernel, dim3((unsigned)B), dim3(64), c->lds_bytes, stream, sa);
-            } else if (c->spec_aot) {
-                if (int rc = set_lds_limit(lms_spec_appendix_c_m512_kernel, c->lds_bytes)) return rc;
-                hipLaunchKernelGGL(lms_spec_appendix_c_m512_kernel, dim3((unsigned)B), dim3(512), c->lds_bytes, stream, sa);
-            } else {
-                void *kargs[] = {&sa};
-                HIP_TRY(hipModuleLaunchKernel(c->jit->fn, (unsigned)B, 1, 1, (unsigned)c->spec_threads, 1, 1, (unsigned)c->lds_bytes, stream,
-                                              kargs, nullptr));
-            }
-        } else if (c->multiwave) {
-            auto k = ldpc::lms_layered_kernel<kRHM, kRWM, true>;
-            if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
-            hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
-        } else {
-            auto k = ldpc::lms_layered_kernel<kRHM, kRWM, false>;
-            if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
-            hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
-        }
-        break;
-    case LDPC_HIP_TASP_DEC: {
+    if (c->spec_aot || c->spec_jit) {
+        // code-specialised kernel: one frame per workgroup
         ldpc_spec::SpecArgs sa{};
         sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
-        if (B > 0x7fffffffLL) return fail(LDPC_HIP_EINVAL, "batch too large");
-        if (c->spec_aot && c->M == 64) hipLaunchKernelGGL(tasp_spec_appendix_c_m64_kernel, dim3((unsigned)B), dim3(64), c->lds_bytes, stream, sa);
-        else if (c->spec_aot) hipLaunchKernelGGL(tasp_spec_appendix_c_m126_kernel, dim3((unsigned)B), dim3(128), c->lds_bytes, stream, sa);
-        else {
-            void *kargs[] = {&sa};
-            HIP_TRY(hipModuleLaunchKernel(c->jit->fn, (unsigned)B, 1, 1, (unsigned)c->spec_threads, 1, 1, (unsigned)c->lds_bytes, stream, kargs, nullptr));
-        }
-        break;
-    }
-    case LDPC_HIP_IMS_DEC:
-        if (c->multiwave) {
-            auto k = ldpc::ims_flood_kernel<kRHM, kNHM, true>;
-            if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
-            hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
+        void *kargs[] = {&sa};
+        if (c->spec_aot) {
+            if (int rc = set_lds_limit(c->spec_aot, c->spec_lds)) return rc;
+            HIP_TRY(hipLaunchKernel(c->spec_aot, dim3((unsigned)B), dim3((unsigned)c->spec_threads), kargs, c->spec_lds, stream));
         } else {
-            auto k = ldpc::ims_flood_kernel<kRHM, kNHM, false>;
-            hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
+            HIP_TRY(hipModuleLaunchKernel(c->spec_jit->fn, (unsigned)B, 1, 1, (unsigned)c->spec_threads, 1, 1, (unsigned)c->spec_lds, stream,
+                                          kargs, nullptr));
         }
-        break;
-    case LDPC_HIP_SP_DEC:
-        if (c->spec_aot || c->jit) {
-            ldpc_spec::SpecArgs sa{};
-            sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
-            if (B > 0x7fffffffLL) return fail(LDPC_HIP_EINVAL, "batch too large");
-            if (c->spec_aot && c->fast_variant == 3) {
-                if (int rc = set_lds_limit(sp_spec_appendix_c_m64_occ2_kernel, c->lds_bytes)) return rc;
-                hipLaunchKernelGGL(sp_spec_appendix_c_m64_occ2_kernel, dim3((unsigned)B), dim3(512), c->lds_bytes, stream, sa);
-            } else if (c->spec_aot) {
-                if (int rc = set_lds_limit(sp_spec_appendix_c_m64_kernel, c->lds_bytes)) return rc;
-                hipLaunchKernelGGL(sp_spec_appendix_c_m64_kernel, dim3((unsigned)B), dim3(512), c->lds_bytes, stream, sa);
+    } else {
+        ldpc::DecArgs a{};
+        a.llr = d_llr; a.hard = d_hard; a.iters = d_iters; a.soft_out = d_soft;
+        a.row_start = c->d_row_start; a.edges = c->d_edges;
+        a.col_start = c->d_col_start; a.col_edges = c->d_col_edges; a.col_slot = c->d_col_slot; a.edge_row = c->d_edge_row;
+        a.B = B; a.rh = c->rh; a.nh = c->nh; a.M = c->M; a.N = c->N; a.F = c->F;
+        a.maxiter = maxiter; a.hard_words = c->hard_words; a.alpha = alpha;
+        a.ims_thr = c->ims_thr; a.ims_qbits = c->ims_qbits; a.ims_dbits = c->ims_dbits;
+        const dim3 grid((unsigned)((B + c->F - 1) / c->F)), block((unsigned)c->threads);
+        void *kargs[] = {&a};
+        const void *k = nullptr;
+        switch (c->decoder_id) {
+        case LDPC_HIP_MS_DEC:
+            if (c->fast_m64) {
+                void *fargs[] = {&a, &c->fast_tab};
+                k = c->variant == 1 ? (const void *)ldpc::ms_flood_m64_kernel<false> : (const void *)ldpc::ms_flood_m64_kernel<true>;
+                HIP_TRY(hipLaunchKernel(k, grid, block, fargs, c->lds_bytes, stream));
+                k = nullptr;
             } else {
-                void *kargs[] = {&sa};
-                HIP_TRY(hipModuleLaunchKernel(c->jit->fn, (unsigned)B, 1, 1, 512, 1, 1, (unsigned)c->lds_bytes, stream, kargs, nullptr));
+                k = c->multiwave ? (const void *)ldpc::ms_flood_kernel<kRHM, kNHM, true> : (const void *)ldpc::ms_flood_kernel<kRHM, kNHM, false>;
             }
             break;
+        case LDPC_HIP_LMS_DEC:
+            k = c->multiwave ? (const void *)ldpc::lms_layered_kernel<kRHM, kRWM, true> : (const void *)ldpc::lms_layered_kernel<kRHM, kRWM, false>;
+            break;
+        case LDPC_HIP_IMS_DEC:
+            k = c->multiwave ? (const void *)ldpc::ims_flood_kernel<kRHM, kNHM, true> : (const void *)ldpc::ims_flood_kernel<kRHM, kNHM, false>;
+            break;
+        case LDPC_HIP_SP_DEC:
+            k = (const void *)ldpc::sp_flood_kernel;
+            break;
+        default:
+            return fail(LDPC_HIP_EUNSUPPORTED, "decoder %d has no generic kernel", c->decoder_id);
         }
-        {
-        auto k = ldpc::sp_flood_kernel;
-        if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
-        hipLaunchKernelGGL(k, grid, block, c->lds_bytes, stream, a);
-        break;
-    }
-    default:
-        return fail(LDPC_HIP_EUNSUPPORTED, "decoder %d", c->decoder_id);
+        if (k) {
+            if (int rc = set_lds_limit(k, c->lds_bytes)) return rc;
+            HIP_TRY(hipLaunchKernel(k, grid, block, kargs, c->lds_bytes, stream));
+        }
     }
     HIP_TRY(hipGetLastError());
     if (c->prof) {

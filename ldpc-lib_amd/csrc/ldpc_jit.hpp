@@ -1,7 +1,7 @@
-// ldpc_jit.hpp -- just-in-time instances of the code-specialised min-sum kernel (ldpc_ms_spec.hpp) via hiprtc.
+// ldpc_jit.hpp -- just-in-time instances of the code-specialised min-sum kernel (ldpc_spec.hpp) via hiprtc.
 //
 // ldpc_hip_open() of an M = 64 min-sum code that is not the ahead-of-time instance writes the constexpr `Code`
-// tables of the opened base matrix as C++ source, compiles ldpc_ms_spec.hpp against them for gfx950 and keeps the
+// tables of the opened base matrix as C++ source, compiles ldpc_spec.hpp against them for gfx950 and keeps the
 // code object in a per-process cache keyed by (device, base matrix).  hiprtc is loaded lazily with dlopen; when it
 // (or the header next to the library) is unavailable the caller keeps using the table-driven kernel
 // (ldpc_ms_fast.hpp) -- still a HIP kernel, never a CPU path.
@@ -116,19 +116,19 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
 
     Rtc *r = rtc(err);
     if (!r) return nullptr;
-    const std::string hdr_path = this_library_dir() + "/csrc/ldpc_ms_spec.hpp";
+    const std::string hdr_path = this_library_dir() + "/csrc/ldpc_spec.hpp";
     std::ifstream hf(hdr_path);
     if (!hf) { err = "cannot read " + hdr_path; return nullptr; }
     std::stringstream hs;
     hs << hf.rdbuf();
     const std::string hdr = hs.str();
-    const std::string src = "#include \"ldpc_ms_spec.hpp\"\nnamespace {\n" + code +
+    const std::string src = "#include \"ldpc_spec.hpp\"\nnamespace {\n" + code +
                             "}\nextern \"C\" __global__ void __launch_bounds__(" + std::to_string(threads) + (std::string(body) == "sp_body" ? ", 4" : std::string(body) == "tasp_body" ? ", 1" : ", 2") + ") spec_jit(const ldpc_spec::SpecArgs a) {\n"
                             "    ldpc_spec::" + body + "<Code>(a);\n}\n";
     hiprtcProgram prog = nullptr;
     const char *hdr_src[] = {hdr.c_str()};
-    const char *hdr_name[] = {"ldpc_ms_spec.hpp"};
-    if (r->CreateProgram(&prog, src.c_str(), "ldpc_ms_spec_jit.hip", 1, hdr_src, hdr_name) != 0) { err = "hiprtcCreateProgram failed"; return nullptr; }
+    const char *hdr_name[] = {"ldpc_spec.hpp"};
+    if (r->CreateProgram(&prog, src.c_str(), "ldpc_spec_jit.hip", 1, hdr_src, hdr_name) != 0) { err = "hiprtcCreateProgram failed"; return nullptr; }
     // -ffp-contract=off is part of the numerics contract (two roundings in y + s*alpha)
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
     const int rc = r->CompileProgram(prog, 4, opts);

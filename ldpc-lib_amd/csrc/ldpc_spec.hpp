@@ -1,4 +1,4 @@
-// ldpc_ms_spec.hpp -- code-specialised decoders: flooding min-sum for lifting M = 64 (one frame == one wavefront)
+// ldpc_spec.hpp -- code-specialised decoders: flooding min-sum for lifting M = 64 (one frame == one wavefront)
 // and layered min-sum for any M <= 512 (one frame == one workgroup).
 //
 // The Tanner graph is a compile-time constant of this kernel: a `Code` type carries the base matrix (block row
