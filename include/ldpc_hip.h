@@ -68,7 +68,8 @@ const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *ctx);
  *   IMS_DEC: imin_sum_decod_qc_lm(st, y, decword, maxiter, decision, alpha, thr, qbits, dbits)  (int16 min-sum)
  *   TASP_DEC: tdmp_sum_prod_gf2_decod_qc_lm(st, soft, decword, maxiter, decision)  (d_soft = final P(bit=1); `decision` dead)
  * All pointers are DEVICE pointers on ctx's device; the work is enqueued on `stream` (a hipStream_t, NULL =
- * default stream) and is asynchronous.
+ * default stream) and is asynchronous.  maxiter must be >= 1 (upstream's behaviour for maxiter <= 0 is an artefact of
+ * stale state and is not reproduced: LDPC_HIP_EINVAL).  LLRs must be finite.
  *   d_llr   [B][N] float64 in.   NOT modified (upstream SP clobbers its input; the clobbered values are what
  *           d_soft receives, see below)
  *   d_hard  [B][ceil(N/32)] uint32 out: bit (v%32) of word v/32 = hard decision of variable v

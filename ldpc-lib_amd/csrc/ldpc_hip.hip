@@ -389,6 +389,9 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
     if (B == 0) return 0;  // empty batch: nothing to do (an empty device tensor has a null pointer)
     if (!d_llr) return fail(LDPC_HIP_EINVAL, "ldpc_hip_decode_dev: null llr");
     if (B > 0x7fffffffLL) return fail(LDPC_HIP_EINVAL, "batch too large");
+    // upstream's decoders with maxiter <= 0 return on a syndrome computed into stale state and leave decword untouched
+    // (decoders.cpp:4602-4625,4766): there is nothing meaningful to reproduce, so it is rejected instead
+    if (maxiter < 1) return fail(LDPC_HIP_EINVAL, "ldpc_hip_decode_dev: maxiter must be >= 1 (got %d)", maxiter);
     if (int rc = set_device(c)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
 

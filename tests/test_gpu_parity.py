@@ -146,6 +146,8 @@ def test_maxiter_one_and_unsupported_shapes(L):
         with L.LdpcHip(dec_id, H, 64) as dec:
             d, it, _ = dec.decode_host(llr, 1)
             assert np.array_equal(it, it_ref) and np.array_equal(d, d_ref)
+    with L.LdpcHip(MS_DEC, H, 64) as dec, pytest.raises(L.LdpcHipError):
+        dec.decode_host(llr, 0)  # maxiter < 1 is rejected, not guessed at
     with pytest.raises(L.LdpcHipError):
         L.LdpcHip(6, H, 64)  # FHT_DEC (GF(q)) is out of scope: fails loudly, no fallback
     with pytest.raises(L.LdpcHipError):
