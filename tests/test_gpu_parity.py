@@ -432,3 +432,15 @@ def test_sum_product_specialised_instances(L, torch):
         assert np.array_equal(iters.cpu().numpy(), it_ref)
         assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
         np.testing.assert_allclose(soft.cpu().numpy(), s_ref, rtol=SP_RTOL)
+
+
+def test_c_example_runs(L, tmp_path):
+    """the plain-C example (examples/simulate.c) end to end: FER at 2.0 dB within the Monte-Carlo spread of upstream's 0.0425"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "simulate")
+    subprocess.check_call(["gcc", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "simulate.c"), "-o", exe,
+                           "-L", os.path.join(root, "ldpc-lib_amd"), "-lldpc_hip", "-Wl,-rpath," + os.path.join(root, "ldpc-lib_amd")])
+    out = subprocess.check_output([exe, os.path.join(GOLDEN_DIR, "h16x32_m126.txt"), "64", "3", "50", "2.0", "2.0", "1", "100000"]).decode()
+    row = [ln for ln in out.splitlines() if not ln.startswith("#")][0].split()
+    assert abs(float(row[1]) - 0.0425) < 0.004, out

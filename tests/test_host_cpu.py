@@ -149,3 +149,12 @@ def test_two_rank_gloo_run_matches_single_process():
     for o in outs:
         line = [ln for ln in o.splitlines() if ln.startswith("RESULT")][0]
         assert json.loads(line.split(" ", 2)[2]) == want
+
+
+def test_c_example_builds_against_the_header(tmp_path):
+    """examples/simulate.c is plain C: the header must be C-clean and the library must link from gcc."""
+    exe = tmp_path / "simulate"
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "simulate.c"),
+                           "-o", str(exe), "-L", os.path.join(ROOT, "ldpc-lib_amd"), "-lldpc_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "ldpc-lib_amd")])
+    assert exe.exists()
