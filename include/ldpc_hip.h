@@ -31,6 +31,7 @@ extern "C" {
 
 /* decoders.h:16-28 enum DEC_ID (only the binary decoders on the hot path are built) */
 #define LDPC_HIP_SP_DEC 1  /* sum_prod_decod_qc_lm   decoders.cpp:1923 */
+#define LDPC_HIP_ASP_DEC 2 /* sum_prod_gf2_decod_qc_lm decoders.cpp:2324 (probability-domain flooding sum-product) */
 #define LDPC_HIP_MS_DEC 3  /* min_sum_decod_qc_lm    decoders.cpp:4554 */
 #define LDPC_HIP_IMS_DEC 4 /* imin_sum_decod_qc_lm   decoders.cpp:5430 */
 #define LDPC_HIP_TASP_DEC 7 /* tdmp_sum_prod_gf2_decod_qc_lm decoders.cpp:2584 (decoder_type of the shipped scenario files) */
@@ -66,6 +67,7 @@ const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *ctx);
  *   LMS_DEC: lmin_sum_decod_qc_lm(st, y, decword, maxiter, decision, alpha, beta)   (alpha, beta dead upstream)
  *   SP_DEC : sum_prod_decod_qc_lm(st, soft, decword, maxiter, decision)
  *   IMS_DEC: imin_sum_decod_qc_lm(st, y, decword, maxiter, decision, alpha, thr, qbits, dbits)  (int16 min-sum)
+ *   ASP_DEC: sum_prod_gf2_decod_qc_lm(st, soft, decword, maxiter, decision)       (d_soft = a-posteriori P(bit=1))
  *   TASP_DEC: tdmp_sum_prod_gf2_decod_qc_lm(st, soft, decword, maxiter, decision)  (d_soft = final P(bit=1); `decision` dead)
  * All pointers are DEVICE pointers on ctx's device; the work is enqueued on `stream` (a hipStream_t, NULL =
  * default stream) and is asynchronous.  maxiter must be >= 1 (upstream's behaviour for maxiter <= 0 is an artefact of

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 # decoders.h:16-28 enum DEC_ID
-DEC_SP, DEC_MS, DEC_IMS, DEC_TASP, DEC_LMS = 1, 3, 4, 7, 8
+DEC_SP, DEC_ASP, DEC_MS, DEC_IMS, DEC_TASP, DEC_LMS = 1, 2, 3, 4, 7, 8
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG_DIR)

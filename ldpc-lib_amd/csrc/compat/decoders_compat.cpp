@@ -44,7 +44,7 @@ Impl *impl_of(const void *st) {
 }
 
 [[noreturn]] void not_built(const char *what) {
-    fprintf(stderr, "%s is not built in ldpc-lib_amd (built decoders: SP_DEC=1, MS_DEC=3, IMS_DEC=4, TASP_DEC=7, LMS_DEC=8)\n", what);
+    fprintf(stderr, "%s is not built in ldpc-lib_amd (built decoders: SP_DEC=1, ASP_DEC=2, MS_DEC=3, IMS_DEC=4, TASP_DEC=7, LMS_DEC=8)\n", what);
     exit(1);  // upstream's die() convention (commons_portable.cpp:181-189)
 }
 
@@ -71,8 +71,8 @@ int decode_common(DEC_STATE *st, int expect_id, double *soft, double *decword, i
 }  // namespace
 
 DEC_STATE *decod_open(int codec_id, int q_bits, int mh, int nh, int M) {
-    if (codec_id != SP_DEC && codec_id != MS_DEC && codec_id != LMS_DEC && codec_id != IMS_DEC && codec_id != TASP_DEC) {
-        fprintf(stderr, "decod_open: decoder id %d is not built in ldpc-lib_amd (built: SP_DEC=1, MS_DEC=3, IMS_DEC=4, TASP_DEC=7, LMS_DEC=8)\n", codec_id);
+    if (codec_id != SP_DEC && codec_id != MS_DEC && codec_id != LMS_DEC && codec_id != IMS_DEC && codec_id != TASP_DEC && codec_id != ASP_DEC) {
+        fprintf(stderr, "decod_open: decoder id %d is not built in ldpc-lib_amd (built: SP_DEC=1, ASP_DEC=2, MS_DEC=3, IMS_DEC=4, TASP_DEC=7, LMS_DEC=8)\n", codec_id);
         return NULL;  // decoders.cpp:786: unknown id -> NULL
     }
     if (mh <= 0 || nh <= 0 || M <= 0) return NULL;
@@ -145,7 +145,9 @@ int ldpc_decod_batch(DEC_STATE *st, double *soft, double *decword, int *iters, l
 }
 
 int bp_decod_qc_lm(DEC_STATE *, double[], double[], int, int) { not_built("bp_decod_qc_lm (BP_DEC)"); }
-int sum_prod_gf2_decod_qc_lm(DEC_STATE *, double[], double[], int, int) { not_built("sum_prod_gf2_decod_qc_lm (ASP_DEC)"); }
+int sum_prod_gf2_decod_qc_lm(DEC_STATE *st, double soft[], double decword[], int maxsteps, int decision) {
+    return decode_common(st, ASP_DEC, soft, decword, nullptr, 1, maxsteps, decision, 0.0);  // soft[] is clobbered with P(bit=1)
+}
 int imin_sum_decod_qc_lm(DEC_STATE *st, double y[], double decword[], int maxsteps, int decision, double alpha, double thr,
                          int qbits, int dbits) {
     Impl *im = impl_of(st);

@@ -64,6 +64,7 @@ LDPC_AOT_KERNEL(lms_spec_appendix_c_m64_kernel, lms_body, CodeAppendixCM64, 64, 
 LDPC_AOT_KERNEL(lms_spec_appendix_c_m512_kernel, lms_body, CodeAppendixCM512, 512, 2)
 // two frames per CU (<= 128 VGPRs, a few spills) beats one frame with 243 VGPRs: 4.18 vs 3.70 M frames/s at 2 dB
 LDPC_AOT_KERNEL(sp_spec_appendix_c_m64_kernel, sp_body, CodeAppendixCM64, 512, 4)
+LDPC_AOT_KERNEL(asp_spec_appendix_c_m64_kernel, asp_body, CodeAppendixCM64, 512, 4)
 LDPC_AOT_KERNEL(tasp_spec_appendix_c_m64_kernel, tasp_body, CodeAppendixCM64, 64, 1)
 LDPC_AOT_KERNEL(tasp_spec_appendix_c_m126_kernel, tasp_body, CodeAppendixCM126, 128, 1)
 
@@ -140,6 +141,7 @@ const AotInstance kAot[] = {
     {LDPC_HIP_LMS_DEC, (const void *)lms_spec_appendix_c_m64_kernel, 64, "lms_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_LMS_DEC, (const void *)lms_spec_appendix_c_m512_kernel, 512, "lms_spec_appendix_c_m512_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM512>},
     {LDPC_HIP_SP_DEC, (const void *)sp_spec_appendix_c_m64_kernel, 512, "sp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
+    {LDPC_HIP_ASP_DEC, (const void *)asp_spec_appendix_c_m64_kernel, 512, "asp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_TASP_DEC, (const void *)tasp_spec_appendix_c_m64_kernel, 64, "tasp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_TASP_DEC, (const void *)tasp_spec_appendix_c_m126_kernel, 128, "tasp_spec_appendix_c_m126_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM126>},
 };
@@ -240,6 +242,14 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
         if (M % 64 == 0 && lds <= 160 * 1024) { p.body = "sp_body"; p.threads = 512; p.lds = lds; }
         break;
     }
+    case LDPC_HIP_ASP_DEC: {
+        p.required = true;  // code-specialised instances only; upstream's all-columns-of-weight-2 branch (decoders.cpp:2431-2480) is not built
+        const size_t lds = sizeof(double) * (size_t)t.ne * M + (((size_t)N + 15) & ~(size_t)15) + 16;
+        bool all_cw2 = true;
+        for (int k = 0; k < t.nh; ++k) all_cw2 = all_cw2 && (t.col_start[k + 1] - t.col_start[k] == 2);
+        if (M % 64 == 0 && t.min_rw >= 2 && !all_cw2 && lds <= 160 * 1024) { p.body = "asp_body"; p.threads = 512; p.lds = lds; }
+        break;
+    }
     case LDPC_HIP_TASP_DEC:
         p.required = true;  // per-edge state lives in VGPRs of the check lane: code-specialised instances only
         if (M <= 256 && t.min_rw >= 2 && t.ne <= 144 && soft_lds <= 64 * 1024) { p.body = "tasp_body"; p.threads = 64 * W; p.lds = soft_lds; }
@@ -267,8 +277,8 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
     if (out) *out = nullptr;
     if (!out || !hd || rh <= 0 || nh <= 0 || M <= 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_open: bad argument");
     if (decoder_id != LDPC_HIP_MS_DEC && decoder_id != LDPC_HIP_LMS_DEC && decoder_id != LDPC_HIP_SP_DEC && decoder_id != LDPC_HIP_IMS_DEC &&
-        decoder_id != LDPC_HIP_TASP_DEC)
-        return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_open: decoder id %d is not built (built: SP=1, MS=3, IMS=4, TASP=7, LMS=8)", decoder_id);
+        decoder_id != LDPC_HIP_TASP_DEC && decoder_id != LDPC_HIP_ASP_DEC)
+        return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_open: decoder id %d is not built (built: SP=1, ASP=2, MS=3, IMS=4, TASP=7, LMS=8)", decoder_id);
     if (M >= 65536 || nh >= 65536) return fail(LDPC_HIP_EUNSUPPORTED, "M and nh must be < 65536");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -466,8 +476,8 @@ int ldpc_hip_decode_host(ldpc_hip_ctx *c, double *llr, long long B, int maxiter,
     if (B == 0) return 0;
     if (int rc = set_device(c)) return rc;
     const bool sp = c->decoder_id == LDPC_HIP_SP_DEC;
-    const bool tasp = c->decoder_id == LDPC_HIP_TASP_DEC;
-    if (tasp) decision = 0;  // upstream ignores `decision` for this decoder: the result is always hard (decoders.cpp:2737-2738)
+    const bool tasp = c->decoder_id == LDPC_HIP_TASP_DEC || c->decoder_id == LDPC_HIP_ASP_DEC;  // probability-domain decoders
+    if (c->decoder_id == LDPC_HIP_TASP_DEC) decision = 0;  // upstream ignores `decision` for this decoder: the result is always hard (decoders.cpp:2737-2738)
     const bool need_soft = decision != 0 || (sp && clobber_sp_input);
     if (int rc = ensure_workspace(c, B, need_soft)) return rc;
     const size_t nllr = (size_t)B * c->N;
@@ -531,7 +541,7 @@ int ldpc_hip_awgn_llr_dev(ldpc_hip_ctx *c, double snr_db, int modulation_type, i
     if (int rc = awgn_sigma(c, snr_db, modulation_type, punctured_blocks, &a.sigma)) return rc;
     a.llr = d_llr; a.B = B; a.first_frame = first_frame; a.N = c->N;
     a.punct_start = c->N - c->M * punctured_blocks;
-    a.punct_val = (c->decoder_id == LDPC_HIP_SP_DEC || c->decoder_id == LDPC_HIP_TASP_DEC) ? 0.0 : 0.5;  // :700 (sic), out_type :451-466
+    a.punct_val = (c->decoder_id == LDPC_HIP_SP_DEC || c->decoder_id == LDPC_HIP_TASP_DEC || c->decoder_id == LDPC_HIP_ASP_DEC) ? 0.0 : 0.5;  // :700 (sic), out_type :451-466
     a.seed = seed;
     const long long total = B * (long long)((c->N + 1) / 2);
     long long blocks = (total + 255) / 256;

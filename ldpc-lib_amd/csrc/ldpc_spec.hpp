@@ -848,4 +848,159 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Flooding sum-product in the probability domain ("advanced sum-product", upstream sum_prod_gf2_decod_qc_lm,
+// decoders.cpp:2324-2581, decoder id 2; general branch :2482-2556 -- codes whose block columns all have weight 2
+// take a different upstream branch and are rejected by the host).  Same work split as sp_body: 8 waves per frame,
+// block rows dealt round-robin, block columns dealt at compile time so that every wave carries the same number of
+// edges.  Per-edge state (one fp64 per edge and CHECK position, upstream's state[slot][check]) in LDS.
+//   1 (row units)     map_bin over the row's edges at check n (:2191-2228): products only
+//   2 (column units)  P1 = p * prod d, P0 = (1-p) * prod (1-d) over the column's edges, rows ascending, d read at
+//                     check (t - c) mod M; soft_out = P1/(P0+P1); then per edge p1 = so/d, p0 = (1-so)/(1-d),
+//                     state <- clamp(p1/(p1+p0), 1e-6, 1-1e-6)                                  (:2488-2556)
+//   3 (row units)     syndrome of soft_out > 0.5
+// exp() of the channel transform is ocml's: probabilities agree with the reference to rounding (same tolerance as
+// TASP), hard decisions and step counts are identical on all test sets.
+// ---------------------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void asp_body(const SpecArgs &a) {
+    static_assert(C::M % 64 == 0, "asp_body: lifting must be a multiple of 64");
+    constexpr SpView<C> V{};
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, CH = M / 64, T = kSpWaves * 64;
+    constexpr int NE = V.ne, UMAX = V.units_max;
+    extern __shared__ double lds[];
+    char *const stb = reinterpret_cast<char *>(lds);                         // state[e][n] at e*M*8 + n*8
+    unsigned char *const hb = reinterpret_cast<unsigned char *>(stb + (size_t)NE * M * 8);  // [N] soft_out > 0.5
+    int *const flag = reinterpret_cast<int *>(hb + ((N + 15) & ~15));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long fr = blockIdx.x;
+
+    auto mind = [](double x, double y) { return x < y ? x : y; };
+    auto maxd = [](double x, double y) { return x < y ? y : x; };
+    auto vote = [&](bool fail) -> bool {
+        if (threadIdx.x == 0) *flag = 0;
+        __syncthreads();
+        if (__ballot(fail) != 0ull && lane == 0) atomicOr(flag, 1);
+        __syncthreads();
+        const bool r = *flag != 0;
+        __syncthreads();
+        return r;
+    };
+    auto syndrome_fail = [&]() -> bool {
+        bool f = false;
+        static_for<0, RH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
+            if (wave == u % kSpWaves) {
+                const int n = ch * 64 + lane;
+                unsigned sy = 0;
+                static_for<0, C::RW[j]>([&](auto S) {
+                    constexpr int s = decltype(S)::value;
+                    int t = n + C::SH[j][s]; if (t >= M) t -= M;
+                    sy ^= hb[C::COL[j][s] * M + t];
+                });
+                f |= sy != 0;
+            }
+        });
+        return f;
+    };
+
+    double p1ch[UMAX], so[UMAX];   // channel P(bit=1) and a-posteriori probability of this wave's own columns
+    static_for<0, UMAX>([&](auto Q) { p1ch[decltype(Q)::value] = 0.5; so[decltype(Q)::value] = 0.5; });
+    static_for<0, NH * CH>([&](auto U) {
+        constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
+        if (wave == V.col_wave[u]) {
+            const int t = ch * 64 + lane;
+            const double x = a.llr[fr * N + k * M + t] * 0.5;                 // :2351-2358
+            const double y = maxd(mind(x, 20.0), -20.0);
+            const double e0 = exp(y), e1 = exp(-y);
+            const double p = e1 / (e0 + e1);
+            p1ch[q] = so[q] = p;
+            hb[k * M + t] = p > 0.5;
+            static_for<0, V.cw[k]>([&](auto X) {                              // :2361-2379 state <- rotated channel probability
+                constexpr int x2 = decltype(X)::value;
+                int nn = t - V.cc[k][x2]; if (nn < 0) nn += M;
+                *reinterpret_cast<double *>(stb + (size_t)V.ce[k][x2] * M * 8 + nn * 8) = p;
+            });
+        }
+    });
+    __syncthreads();
+
+    int res = 0;
+    bool fail = vote(syndrome_fail());                                        // :2393-2399
+    int steps = 0;
+    while (fail && steps < a.maxiter) {
+        // ---- phase 1: check nodes
+        static_for<0, RH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH, RW = C::RW[j];
+            static_assert(RW >= 2, "asp_body: map_bin needs at least two edges per check");
+            if (wave == u % kSpWaves) {
+                const int n8 = (ch * 64 + lane) * 8;
+                double P[RW], SF[RW], SB[RW];
+                static_for<0, RW>([&](auto S) {
+                    constexpr int s = decltype(S)::value;
+                    P[s] = 1 - 2 * *reinterpret_cast<const double *>(stb + (size_t)(V.row_off[j] + s) * M * 8 + n8);  // :2206
+                });
+                SF[0] = P[0];
+                static_for<1, RW - 1>([&](auto I) { constexpr int i = decltype(I)::value; SF[i] = P[i] * SF[i - 1]; });
+                SB[RW - 1] = P[RW - 1];
+                static_for<0, RW - 2>([&](auto I) { constexpr int i = RW - 2 - decltype(I)::value; SB[i] = P[i] * SB[i + 1]; });
+                *reinterpret_cast<double *>(stb + (size_t)(V.row_off[j] + 0) * M * 8 + n8) = (1 - SB[1]) / 2;
+                static_for<1, RW - 1>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    *reinterpret_cast<double *>(stb + (size_t)(V.row_off[j] + i) * M * 8 + n8) = (1 - SF[i - 1] * SB[i + 1]) / 2;
+                });
+                *reinterpret_cast<double *>(stb + (size_t)(V.row_off[j] + RW - 1) * M * 8 + n8) = (1 - SF[RW - 2]) / 2;
+            }
+        });
+        __syncthreads();
+        // ---- phase 2: symbol nodes + local data update
+        static_for<0, NH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u], CW = V.cw[k];
+            if (wave == V.col_wave[u]) {
+                const int t = ch * 64 + lane;
+                double d[CW];
+                double P1 = p1ch[q], P0 = 1 - p1ch[q];                        // :2492-2496
+                static_for<0, CW>([&](auto X) {
+                    constexpr int x = decltype(X)::value;
+                    int nn = t - V.cc[k][x]; if (nn < 0) nn += M;
+                    d[x] = *reinterpret_cast<const double *>(stb + (size_t)V.ce[k][x] * M * 8 + nn * 8);
+                    P1 *= d[x];                                               // :2511-2512, rows ascending
+                    P0 *= 1 - d[x];
+                });
+                const double sov = P1 / (P0 + P1);                            // :2519
+                so[q] = sov;
+                hb[k * M + t] = sov > 0.5;
+                static_for<0, CW>([&](auto X) {                               // :2540-2548
+                    constexpr int x = decltype(X)::value;
+                    int nn = t - V.cc[k][x]; if (nn < 0) nn += M;
+                    const double p1 = sov / d[x];
+                    const double p0 = (1 - sov) / (1 - d[x]);
+                    const double dd = p1 / (p1 + p0);
+                    *reinterpret_cast<double *>(stb + (size_t)V.ce[k][x] * M * 8 + nn * 8) = maxd(mind(dd, 1.0 - 0.000001), 0.000001);
+                });
+            }
+        });
+        __syncthreads();
+        fail = vote(syndrome_fail());                                         // :2566
+        steps = steps + 1;
+    }
+    res = fail ? -steps : (steps == 0 ? 0 : steps);                           // 0: input codeword; steps+1 upstream == steps here
+
+    if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
+    if (a.hard) {
+        for (int w = threadIdx.x; w < N / 32; w += T) {
+            u32 bits = 0;
+            for (int b = 0; b < 32; ++b) bits |= (u32)hb[32 * w + b] << b;
+            a.hard[fr * (N / 32) + w] = bits;
+        }
+    }
+    if (a.soft_out) {
+        static_for<0, NH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
+            if (wave == V.col_wave[u]) a.soft_out[fr * N + k * M + ch * 64 + lane] = so[q];
+        });
+    }
+}
+
 }  // namespace ldpc_spec

@@ -476,6 +476,83 @@ int orc_tdmp_sum_prod(orc_code *c, double *soft, double *decword, int maxsteps, 
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * Flooding sum-product in the probability domain ("advanced sum-product"): decoders.cpp:2324-2581
+ * ------------------------------------------------------------------------------------------- */
+int orc_sum_prod_gf2(orc_code *c, double *soft, double *decword, int maxsteps, int decision) {
+    const int M = c->M, N = c->N, rh = c->rh, nh = c->nh;
+    double *so = c->soft;   /* soft_out */
+    double *st = c->ZZ;     /* state[edge block][CHECK position n] (reference: state[slot][j*M+n]) */
+    double a[64], P[64], SF[64], SB[64];
+    int v, e, j, n, i, q, steps, synd, all2 = 1;
+
+    for (i = 0; i < nh; i++) if (c->col_start[i + 1] - c->col_start[i] != 2) all2 = 0;
+    if (all2) return -9999; /* :2431-2480 uses different arithmetic; not restated */
+
+    for (v = 0; v < N; v++) { /* :2351-2358 */
+        double x = soft[v] * 0.5;
+        double y = orc_maxd(orc_mind(x, 20.0), -20.0);
+        double e0 = exp(y), e1 = exp(-y);
+        soft[v] = e1 / (e0 + e1);
+    }
+    for (e = 0; e < c->ne; e++) { /* :2361-2379 */
+        const double *col = soft + c->e_col[e] * M;
+        for (n = 0; n < M; n++) st[(size_t)e * M + n] = col[ROT(n, c->e_shift[e], M)];
+    }
+    for (v = 0; v < N; v++) so[v] = soft[v];
+    synd = orc_syndrome_thr(c, so, 0.5); /* :2393 */
+    if (synd == 0) {
+        for (v = 0; v < N; v++) decword[v] = decision ? so[v] : (double)(so[v] > 0.5);
+        return 0;
+    }
+    steps = 0;
+    while (steps < maxsteps) {
+        for (j = 0; j < rh; j++) { /* check nodes :2406-2428 */
+            const int e0 = c->row_start[j], rw = c->row_start[j + 1] - e0;
+            for (n = 0; n < M; n++) {
+                int s;
+                for (s = 0; s < rw; s++) a[s] = st[(size_t)(e0 + s) * M + n];
+                orc_map_bin(a, rw, P, SF, SB);
+                for (s = 0; s < rw; s++) st[(size_t)(e0 + s) * M + n] = a[s];
+            }
+        }
+        for (i = 0; i < nh; i++) { /* symbol nodes, overall products :2488-2520 */
+            for (n = 0; n < M; n++) {
+                double P1 = soft[i * M + n], P0 = 1 - soft[i * M + n];
+                for (q = c->col_start[i]; q < c->col_start[i + 1]; q++) {
+                    const int ee = c->col_edge[q];
+                    int nn = n - c->e_shift[ee]; if (nn < 0) nn += M; /* rotate by m-circ */
+                    const double d = st[(size_t)ee * M + nn];
+                    P1 *= d;
+                    P0 *= 1 - d;
+                }
+                so[i * M + n] = P1 / (P0 + P1);
+            }
+        }
+        for (i = 0; i < nh; i++) { /* local data updating :2523-2556 */
+            for (q = c->col_start[i]; q < c->col_start[i + 1]; q++) {
+                const int ee = c->col_edge[q];
+                for (n = 0; n < M; n++) {
+                    int nn = n - c->e_shift[ee]; if (nn < 0) nn += M;
+                    const double sov = so[i * M + n], sos = st[(size_t)ee * M + nn];
+                    const double p1 = sov / sos;
+                    const double p0 = (1 - sov) / (1 - sos);
+                    const double d = p1 / (p1 + p0);
+                    st[(size_t)ee * M + nn] = orc_maxd(orc_mind(d, 1.0 - 0.000001), 0.000001); /* SP_DEC_MAX/MIN_VAL :96-97 */
+                }
+            }
+        }
+        synd = orc_syndrome_thr(c, so, 0.5); /* :2566 */
+        if (synd == 0) {
+            for (v = 0; v < N; v++) decword[v] = decision ? so[v] : (double)(so[v] > 0.5);
+            return steps + 1;
+        }
+        steps = steps + 1;
+    }
+    for (v = 0; v < N; v++) decword[v] = decision ? so[v] : (double)(so[v] > 0.5);
+    return -steps;
+}
+
+/* ---------------------------------------------------------------------------------------------
  * Integer min-sum: decoders.cpp:5430-5690 (MS_MUL_CORRECTION, MS_ALPHA_FPP = 4, decoders.h:13-14)
  * ------------------------------------------------------------------------------------------- */
 static short orc_limit(int x, short mx) { return (short)(x > mx ? mx : (x < -mx ? -mx : x)); } /* :4308 */

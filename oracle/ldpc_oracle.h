@@ -58,6 +58,12 @@ int orc_imin_sum(orc_code *c, const double *y, double *decword, int maxsteps, in
  * returns 0 if the input already is a codeword, steps (>0) when the syndrome cleared, -steps otherwise. */
 int orc_tdmp_sum_prod(orc_code *c, double *soft, double *decword, int maxsteps, double *post_out);
 
+/* decoders.cpp:2324-2581 sum_prod_gf2_decod_qc_lm ("ASP", decoder id 2): flooding sum-product in the probability
+ * domain, general branch (:2482-2556; the all-columns-of-weight-2 shortcut :2431-2480 is not restated and such codes
+ * are rejected with -9999).  soft[] is CLOBBERED with P(bit=1) of the channel (:2351-2358); decword = soft_out > 0.5
+ * or soft_out (decision != 0).  returns 0 / steps+1 / -steps. */
+int orc_sum_prod_gf2(orc_code *c, double *soft, double *decword, int maxsteps, int decision);
+
 /* Syndrome of hard decisions (soft<0) : decoders.cpp:793-814 check_syndrome. returns 1 if any check fails. */
 int orc_syndrome_nonzero(const orc_code *c, const double *soft);
 

@@ -17,7 +17,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from ldpc_testlib import (GOLDEN_DIR, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Reference, awgn_llr, load_base_matrix,  # noqa: E402
+from ldpc_testlib import (ASP_DEC, GOLDEN_DIR, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Reference, awgn_llr, load_base_matrix,  # noqa: E402
                           oracle_lib, pack_bits, ref_lib, relift, _as_double_p)
 
 SETS = [
@@ -42,6 +42,9 @@ SETS = [
     ("tasp_m64_1p7",   TASP_DEC, 64,  1.7, 24, 15, 4),
     ("tasp_m64_1p0",   TASP_DEC, 64,  1.0, 12, 50, 2),
     ("tasp_m1_4p0",    TASP_DEC, 1,   4.0, 64, 20, 8),
+    ("asp_m64_2p0",    ASP_DEC, 64,  2.0, 24, 50, 4),   # probability-domain flooding sum-product (decoder 2)
+    ("asp_m64_1p2",    ASP_DEC, 64,  1.2, 12, 50, 2),
+    ("asp_m128_1p7",   ASP_DEC, 128, 1.7, 8,  30, 2),
 ]
 ONLY = set(sys.argv[1:])  # optional: regenerate just the named sets
 

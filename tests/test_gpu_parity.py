@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from ldpc_testlib import (GOLDEN_DIR, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Oracle, awgn_llr, bpsk_sigma, load_base_matrix, pack_bits,
+from ldpc_testlib import (ASP_DEC, GOLDEN_DIR, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Oracle, awgn_llr, bpsk_sigma, load_base_matrix, pack_bits,
                           philox_gauss_pairs, relift, syndrome_np, unpack_bits)
 
 pytestmark = pytest.mark.gpu
@@ -52,6 +52,10 @@ def test_golden_vectors_host_api(L, name):
         assert np.array_equal(it1, g["iters"][:ns])
         if dec_id == SP_DEC:
             np.testing.assert_allclose(d1, g["soft"], rtol=SP_RTOL, atol=0)
+        elif dec_id == ASP_DEC:
+            np.testing.assert_allclose(d1, g["soft"], rtol=TASP_RTOL, atol=0)   # a-posteriori P(bit=1)
+            x = np.clip(g["llr"] * 0.5, -20.0, 20.0)  # the input is left holding the channel P(bit=1) (decoders.cpp:2351-2358)
+            np.testing.assert_allclose(after, np.exp(-x) / (np.exp(x) + np.exp(-x)), rtol=1e-14)
         elif dec_id == TASP_DEC:
             assert np.array_equal(d1, g["soft"])    # `decision` is dead upstream: still the hard decisions
             x = np.clip(g["llr"] * 0.5, -20.0, 20.0)  # and the input is left holding P(bit=1) (decoders.cpp:2611-2618)
@@ -79,6 +83,8 @@ def test_golden_vectors_host_api(L, name):
     (TASP_DEC, 126, (1.7,), 24, 15),            # the shipped scenario's lifting, 2 waves per frame
     (TASP_DEC, 40, (2.5,), 60, 30),             # hiprtc instance, 24 idle lanes
     (TASP_DEC, 200, (1.6,), 10, 15),            # hiprtc instance, 4 waves per frame
+    (ASP_DEC, 64, (1.0, 1.6, 2.2), 120, 30),    # probability-domain flooding sum-product (decoder 2), ahead-of-time instance
+    (ASP_DEC, 128, (1.7,), 20, 25),             # hiprtc instance, two 64-lane chunks per block row/column
 ])
 def test_random_batches_against_oracle(L, torch, dec_id, M, snrs, frames, maxiter):
     H = relift(load_base_matrix(), M)
@@ -93,7 +99,7 @@ def test_random_batches_against_oracle(L, torch, dec_id, M, snrs, frames, maxite
         assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
         assert np.array_equal(x.cpu().numpy(), llr)  # the device entry point never modifies its input
         s_ref, _, _ = o.decode(dec_id, llr, maxiter, 1)
-        if dec_id in (SP_DEC, TASP_DEC):  # exp() on the device vs glibc: a-posteriori values to the stated tolerance
+        if dec_id in (SP_DEC, ASP_DEC, TASP_DEC):  # exp() on the device vs glibc: a-posteriori values to the stated tolerance
             np.testing.assert_allclose(soft.cpu().numpy(), s_ref, rtol=SP_RTOL if dec_id == SP_DEC else TASP_RTOL)
         else:
             assert np.array_equal(soft.cpu().numpy(), s_ref)
@@ -148,6 +154,8 @@ def test_maxiter_one_and_unsupported_shapes(L):
             assert np.array_equal(it, it_ref) and np.array_equal(d, d_ref)
     with L.LdpcHip(MS_DEC, H, 64) as dec, pytest.raises(L.LdpcHipError):
         dec.decode_host(llr, 0)  # maxiter < 1 is rejected, not guessed at
+    with pytest.raises(L.LdpcHipError):
+        L.LdpcHip(ASP_DEC, relift(load_base_matrix(), 126), 126)  # ASP instances exist for M % 64 == 0 only: loud, no fallback
     with pytest.raises(L.LdpcHipError):
         L.LdpcHip(6, H, 64)  # FHT_DEC (GF(q)) is out of scope: fails loudly, no fallback
     with pytest.raises(L.LdpcHipError):
@@ -329,6 +337,7 @@ def _compat_lib(L):
     (MS_DEC, 64, 2.5, 50, 10**9, 300, 1.0, 1, 0, 5),        # QAM4 formula (:607-612)
     (MS_DEC, 64, 3.0, 50, 10**9, 200, 1.0, 0, 2, 5),        # two punctured blocks (:697-710)
     (TASP_DEC, 126, 1.7, 15, 50, 10**8, 1.0, 0, 0, 1),      # the shipped `search` scenario: 50 errored frames in 821
+    (ASP_DEC, 64, 1.6, 30, 10**9, 250, 1.0, 0, 0, 2),       # probability-domain sum-product, out_type 1 puncturing value
 ])
 def test_exact_replay_harness_equals_the_sequential_harness(L, dec_id, M, snr, maxit, n_fe, n_exp, ref, mod, punct, seed):
     """C++ bp_simulation on the GPU (batched, host mt19937 noise in upstream's draw order) == the sequential CPU
@@ -354,7 +363,8 @@ def test_exact_replay_harness_equals_the_sequential_harness(L, dec_id, M, snr, m
         assert res.nde == 112 and res.experiment == 2001   # the FER 0.056 the survey measured with the compiled upstream binary
 
 
-@pytest.mark.parametrize("name", ["ms_m64_1p2", "lms_m64_0p8", "sp_m64_2p0", "ms_m126_1p7", "ms_m1_4p0", "ims_m64_2p0", "tasp_m126_1p7"])
+@pytest.mark.parametrize("name", ["ms_m64_1p2", "lms_m64_0p8", "sp_m64_2p0", "ms_m126_1p7", "ms_m1_4p0", "ims_m64_2p0", "tasp_m126_1p7",
+                                  "asp_m64_1p2"])
 def test_decoders_h_call_surface(L, tmp_path, name):
     """decod_open / hd fill / decod_init / <decoder>(st, st->y, st->decword, ...) / decod_close from a C++ program built
     against include/ldpc/decoders.h, on the reference's golden vectors."""
@@ -383,11 +393,11 @@ def test_decoders_h_call_surface(L, tmp_path, name):
         assert np.array_equal(iters, g["iters"][:nfr])
         if decision == 0 or dec_id == TASP_DEC:
             assert np.array_equal(pack_bits(dec), g["hard"][:nfr])
-        elif dec_id == SP_DEC:
-            np.testing.assert_allclose(dec, g["soft"], rtol=SP_RTOL)
+        elif dec_id in (SP_DEC, ASP_DEC):
+            np.testing.assert_allclose(dec, g["soft"], rtol=SP_RTOL if dec_id == SP_DEC else TASP_RTOL)
         else:
             assert np.array_equal(dec, g["soft"])
-        if dec_id not in (SP_DEC, TASP_DEC):
+        if dec_id not in (SP_DEC, ASP_DEC, TASP_DEC):
             assert np.array_equal(after, llr)          # MS/LMS leave y intact (SURVEY 8b ownership)
         else:
             assert not np.array_equal(after, llr)      # SP clobbers its input like upstream (decoders.cpp:1950)
