@@ -86,7 +86,7 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
     int out_type;  // :451-466
     switch (decoder_type) {
     case LDPC_HIP_SP_DEC: case LDPC_HIP_ASP_DEC: case LDPC_HIP_TASP_DEC: out_type = 1; break;
-    case LDPC_HIP_MS_DEC: case LDPC_HIP_LMS_DEC: case LDPC_HIP_IMS_DEC: out_type = 0; break;
+    case LDPC_HIP_BP_DEC: case LDPC_HIP_MS_DEC: case LDPC_HIP_LMS_DEC: case LDPC_HIP_IMS_DEC: out_type = 0; break;
     default: out_type = 0; Env::fail("Unknown decoder type");
     }
     const int QAM = modulation_type == MODULATION_SKIP_ ? 1 : 4, halfmlog = 1;                  // :405-406

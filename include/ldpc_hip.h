@@ -30,6 +30,7 @@ extern "C" {
 #define LDPC_HIP_ABI_VERSION 1
 
 /* decoders.h:16-28 enum DEC_ID (only the binary decoders on the hot path are built) */
+#define LDPC_HIP_BP_DEC 0  /* bp_decod_qc_lm         decoders.cpp:1708 (Gallager BP, log domain) */
 #define LDPC_HIP_SP_DEC 1  /* sum_prod_decod_qc_lm   decoders.cpp:1923 */
 #define LDPC_HIP_ASP_DEC 2 /* sum_prod_gf2_decod_qc_lm decoders.cpp:2324 (probability-domain flooding sum-product) */
 #define LDPC_HIP_MS_DEC 3  /* min_sum_decod_qc_lm    decoders.cpp:4554 */
@@ -67,6 +68,7 @@ const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *ctx);
  *   LMS_DEC: lmin_sum_decod_qc_lm(st, y, decword, maxiter, decision, alpha, beta)   (alpha, beta dead upstream)
  *   SP_DEC : sum_prod_decod_qc_lm(st, soft, decword, maxiter, decision)
  *   IMS_DEC: imin_sum_decod_qc_lm(st, y, decword, maxiter, decision, alpha, thr, qbits, dbits)  (int16 min-sum)
+ *   BP_DEC:  bp_decod_qc_lm(st, soft, decword, maxiter, decision)                  (d_soft = a-posteriori LLR)
  *   ASP_DEC: sum_prod_gf2_decod_qc_lm(st, soft, decword, maxiter, decision)       (d_soft = a-posteriori P(bit=1))
  *   TASP_DEC: tdmp_sum_prod_gf2_decod_qc_lm(st, soft, decword, maxiter, decision)  (d_soft = final P(bit=1); `decision` dead)
  * All pointers are DEVICE pointers on ctx's device; the work is enqueued on `stream` (a hipStream_t, NULL =
@@ -82,6 +84,14 @@ const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *ctx);
  */
 int ldpc_hip_decode_dev(ldpc_hip_ctx *ctx, const double *d_llr, long long B, int maxiter, double alpha,
                         uint32_t *d_hard, int32_t *d_iters, double *d_soft, void *stream);
+
+/* BP_DEC only.  Upstream's bp_decod_qc_lm does not clear DEC_STATE::syndr before its input check (decoders.cpp:1742-1762),
+ * so frame b's check sees the syndrome frame b-1 left behind (non-zero after a failed frame).  With the chain ON (default)
+ * the frames of one ldpc_hip_decode_dev call are decoded as if one after the other on one DEC_STATE, continuing from the
+ * last frame of the previous call on this context; ldpc_hip_decode_dev then synchronises the stream.  on == 0: every
+ * frame starts from a zero syndrome (asynchronous, independent of batching).  reset_carry != 0 forgets the carried
+ * syndrome (what decod_close + decod_open would do). */
+int ldpc_hip_set_bp_chain(ldpc_hip_ctx *ctx, int on, int reset_carry);
 
 /* Integer min-sum only: the quantiser arguments of imin_sum_decod_qc_lm (decoders.h:300; defaults MS_THR 1.4,
  * MS_QBITS 6, MS_DBITS 8 of decoders.h:46-48).  `alpha` of the decode calls gives ialpha = (int)(alpha*16). */

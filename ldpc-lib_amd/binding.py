@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 # decoders.h:16-28 enum DEC_ID
-DEC_SP, DEC_ASP, DEC_MS, DEC_IMS, DEC_TASP, DEC_LMS = 1, 2, 3, 4, 7, 8
+DEC_BP, DEC_SP, DEC_ASP, DEC_MS, DEC_IMS, DEC_TASP, DEC_LMS = 0, 1, 2, 3, 4, 7, 8
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG_DIR)
@@ -82,6 +82,7 @@ def load_library():
     lib.ldpc_hip_qam_demod_dev.argtypes = [i32, f64, f64, vp, i64, vp, i32, i32, vp]
     lib.ldpc_hip_count_errors_dev.argtypes = [vp, vp, vp, i64, vp, vp, vp]
     lib.ldpc_hip_simulate.argtypes = [vp, f64, i32, i32, i32, f64, u64, i64, i64, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.ldpc_hip_set_bp_chain.argtypes = [vp, i32, i32]
     lib.ldpc_hip_profile_enable.argtypes = [vp, i32]
     lib.ldpc_hip_profile_read.argtypes = [vp, C.POINTER(f64), C.POINTER(i64), i32]
     if lib.ldpc_hip_abi_version() != 1:
@@ -124,6 +125,10 @@ class LdpcHip:
         if getattr(self, "h", None):
             self.lib.ldpc_hip_close(self.h)
             self.h = None
+
+    def set_bp_chain(self, on=True, reset_carry=False):
+        """BP_DEC: chain frames through upstream's uncleared syndrome array (include/ldpc_hip.h)."""
+        _check(self.lib, self.lib.ldpc_hip_set_bp_chain(self.h, int(on), int(reset_carry)), "ldpc_hip_set_bp_chain")
 
     def __del__(self):
         try:

@@ -44,7 +44,7 @@ Impl *impl_of(const void *st) {
 }
 
 [[noreturn]] void not_built(const char *what) {
-    fprintf(stderr, "%s is not built in ldpc-lib_amd (built decoders: SP_DEC=1, ASP_DEC=2, MS_DEC=3, IMS_DEC=4, TASP_DEC=7, LMS_DEC=8)\n", what);
+    fprintf(stderr, "%s is not built in ldpc-lib_amd (built decoders: BP_DEC=0, SP_DEC=1, ASP_DEC=2, MS_DEC=3, IMS_DEC=4, TASP_DEC=7, LMS_DEC=8)\n", what);
     exit(1);  // upstream's die() convention (commons_portable.cpp:181-189)
 }
 
@@ -71,8 +71,8 @@ int decode_common(DEC_STATE *st, int expect_id, double *soft, double *decword, i
 }  // namespace
 
 DEC_STATE *decod_open(int codec_id, int q_bits, int mh, int nh, int M) {
-    if (codec_id != SP_DEC && codec_id != MS_DEC && codec_id != LMS_DEC && codec_id != IMS_DEC && codec_id != TASP_DEC && codec_id != ASP_DEC) {
-        fprintf(stderr, "decod_open: decoder id %d is not built in ldpc-lib_amd (built: SP_DEC=1, ASP_DEC=2, MS_DEC=3, IMS_DEC=4, TASP_DEC=7, LMS_DEC=8)\n", codec_id);
+    if (codec_id != SP_DEC && codec_id != MS_DEC && codec_id != LMS_DEC && codec_id != IMS_DEC && codec_id != TASP_DEC && codec_id != ASP_DEC && codec_id != BP_DEC) {
+        fprintf(stderr, "decod_open: decoder id %d is not built in ldpc-lib_amd (built: BP_DEC=0, SP_DEC=1, ASP_DEC=2, MS_DEC=3, IMS_DEC=4, TASP_DEC=7, LMS_DEC=8)\n", codec_id);
         return NULL;  // decoders.cpp:786: unknown id -> NULL
     }
     if (mh <= 0 || nh <= 0 || M <= 0) return NULL;
@@ -144,7 +144,11 @@ int ldpc_decod_batch(DEC_STATE *st, double *soft, double *decword, int *iters, l
     return decode_common(st, st ? st->codec_id : -1, soft, decword, iters, B, maxiter, decision, MS_ALPHA);
 }
 
-int bp_decod_qc_lm(DEC_STATE *, double[], double[], int, int) { not_built("bp_decod_qc_lm (BP_DEC)"); }
+int bp_decod_qc_lm(DEC_STATE *st, double soft[], double decword[], int maxiter, int decision) {
+    // soft[] is upstream's working array: it comes back holding the a-posteriori LLRs.  The context keeps the syndrome
+    // the previous call left behind, like upstream's uncleared st->syndr (decoders.cpp:1742-1762).
+    return decode_common(st, BP_DEC, soft, decword, nullptr, 1, maxiter, decision, 0.0);
+}
 int sum_prod_gf2_decod_qc_lm(DEC_STATE *st, double soft[], double decword[], int maxsteps, int decision) {
     return decode_common(st, ASP_DEC, soft, decword, nullptr, 1, maxsteps, decision, 0.0);  // soft[] is clobbered with P(bit=1)
 }

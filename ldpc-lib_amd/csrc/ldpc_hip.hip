@@ -64,6 +64,7 @@ LDPC_AOT_KERNEL(lms_spec_appendix_c_m64_kernel, lms_body, CodeAppendixCM64, 64, 
 LDPC_AOT_KERNEL(lms_spec_appendix_c_m512_kernel, lms_body, CodeAppendixCM512, 512, 2)
 // two frames per CU (<= 128 VGPRs, a few spills) beats one frame with 243 VGPRs: 4.18 vs 3.70 M frames/s at 2 dB
 LDPC_AOT_KERNEL(sp_spec_appendix_c_m64_kernel, sp_body, CodeAppendixCM64, 512, 4)
+LDPC_AOT_KERNEL(bp_spec_appendix_c_m64_kernel, bp_body, CodeAppendixCM64, 512, 4)
 LDPC_AOT_KERNEL(asp_spec_appendix_c_m64_kernel, asp_body, CodeAppendixCM64, 512, 4)
 LDPC_AOT_KERNEL(tasp_spec_appendix_c_m64_kernel, tasp_body, CodeAppendixCM64, 64, 1)
 LDPC_AOT_KERNEL(tasp_spec_appendix_c_m126_kernel, tasp_body, CodeAppendixCM126, 128, 1)
@@ -141,6 +142,7 @@ const AotInstance kAot[] = {
     {LDPC_HIP_LMS_DEC, (const void *)lms_spec_appendix_c_m64_kernel, 64, "lms_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_LMS_DEC, (const void *)lms_spec_appendix_c_m512_kernel, 512, "lms_spec_appendix_c_m512_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM512>},
     {LDPC_HIP_SP_DEC, (const void *)sp_spec_appendix_c_m64_kernel, 512, "sp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
+    {LDPC_HIP_BP_DEC, (const void *)bp_spec_appendix_c_m64_kernel, 512, "bp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_ASP_DEC, (const void *)asp_spec_appendix_c_m64_kernel, 512, "asp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_TASP_DEC, (const void *)tasp_spec_appendix_c_m64_kernel, 64, "tasp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_TASP_DEC, (const void *)tasp_spec_appendix_c_m126_kernel, 128, "tasp_spec_appendix_c_m126_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM126>},
@@ -169,6 +171,12 @@ struct ldpc_hip_ctx {
     int spec_threads = 64;
     size_t spec_lds = 0;
     std::string kernel_name;  // what this context launches (ldpc_hip_kernel_name)
+    // BP_DEC: upstream's input check sees the syndrome the previous frame left in DEC_STATE::syndr (decoders.cpp:1742-1762)
+    bool bp_chain = true;                 // ldpc_hip_set_bp_chain
+    std::vector<uint32_t> bp_carry;       // [R/32] syndrome left behind by the last frame decoded on this context
+    uint32_t *d_bp_stale = nullptr, *d_bp_synd = nullptr;
+    int32_t *d_bp_idx = nullptr;
+    long long bp_frames = 0;
     // device tables of the generic kernels
     int32_t *d_row_start = nullptr, *d_col_start = nullptr;
     uint32_t *d_edges = nullptr, *d_col_edges = nullptr, *d_col_slot = nullptr, *d_edge_row = nullptr;
@@ -242,6 +250,12 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
         if (M % 64 == 0 && lds <= 160 * 1024) { p.body = "sp_body"; p.threads = 512; p.lds = lds; }
         break;
     }
+    case LDPC_HIP_BP_DEC: {
+        p.required = true;  // code-specialised instances only
+        const size_t lds = (sizeof(double) + 1) * ((size_t)t.ne * M + (size_t)t.rh * M) + (((size_t)N + 15) & ~(size_t)15) + 16;
+        if (M % 64 == 0 && lds <= 160 * 1024) { p.body = "bp_body"; p.threads = 512; p.lds = lds; }
+        break;
+    }
     case LDPC_HIP_ASP_DEC: {
         p.required = true;  // code-specialised instances only; upstream's all-columns-of-weight-2 branch (decoders.cpp:2431-2480) is not built
         const size_t lds = sizeof(double) * (size_t)t.ne * M + (((size_t)N + 15) & ~(size_t)15) + 16;
@@ -277,8 +291,8 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
     if (out) *out = nullptr;
     if (!out || !hd || rh <= 0 || nh <= 0 || M <= 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_open: bad argument");
     if (decoder_id != LDPC_HIP_MS_DEC && decoder_id != LDPC_HIP_LMS_DEC && decoder_id != LDPC_HIP_SP_DEC && decoder_id != LDPC_HIP_IMS_DEC &&
-        decoder_id != LDPC_HIP_TASP_DEC && decoder_id != LDPC_HIP_ASP_DEC)
-        return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_open: decoder id %d is not built (built: SP=1, ASP=2, MS=3, IMS=4, TASP=7, LMS=8)", decoder_id);
+        decoder_id != LDPC_HIP_TASP_DEC && decoder_id != LDPC_HIP_ASP_DEC && decoder_id != LDPC_HIP_BP_DEC)
+        return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_open: decoder id %d is not built (built: BP=0, SP=1, ASP=2, MS=3, IMS=4, TASP=7, LMS=8)", decoder_id);
     if (M >= 65536 || nh >= 65536) return fail(LDPC_HIP_EUNSUPPORTED, "M and nh must be < 65536");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -289,6 +303,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
     c->decoder_id = decoder_id; c->device = device;
     c->rh = rh; c->nh = nh; c->M = M; c->N = nh * M; c->R = rh * M; c->ne = t.ne;
     c->hard_words = (c->N + 31) / 32;
+    c->bp_carry.assign((size_t)(c->R + 31) / 32, 0u);
     const char *venv = getenv("LDPC_HIP_MS_VARIANT");
     c->variant = venv ? atoi(venv) : 2;
 
@@ -383,6 +398,9 @@ void ldpc_hip_close(ldpc_hip_ctx *c) {
     if (c->d_col_slot) (void)hipFree(c->d_col_slot);
     if (c->d_edge_row) (void)hipFree(c->d_edge_row);
     if (c->w_counters) (void)hipFree(c->w_counters);
+    if (c->d_bp_stale) (void)hipFree(c->d_bp_stale);
+    if (c->d_bp_synd) (void)hipFree(c->d_bp_synd);
+    if (c->d_bp_idx) (void)hipFree(c->d_bp_idx);
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete c;
 }
@@ -415,13 +433,62 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
         // code-specialised kernel: one frame per workgroup
         ldpc_spec::SpecArgs sa{};
         sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
-        void *kargs[] = {&sa};
-        if (c->spec_aot) {
-            if (int rc = set_lds_limit(c->spec_aot, c->spec_lds)) return rc;
-            HIP_TRY(hipLaunchKernel(c->spec_aot, dim3((unsigned)B), dim3((unsigned)c->spec_threads), kargs, c->spec_lds, stream));
+        auto launch = [&](long long blocks) -> int {
+            void *kargs[] = {&sa};
+            if (c->spec_aot) {
+                if (int rc = set_lds_limit(c->spec_aot, c->spec_lds)) return rc;
+                HIP_TRY(hipLaunchKernel(c->spec_aot, dim3((unsigned)blocks), dim3((unsigned)c->spec_threads), kargs, c->spec_lds, stream));
+            } else {
+                HIP_TRY(hipModuleLaunchKernel(c->spec_jit->fn, (unsigned)blocks, 1, 1, (unsigned)c->spec_threads, 1, 1, (unsigned)c->spec_lds,
+                                              stream, kargs, nullptr));
+            }
+            return 0;
+        };
+        if (c->decoder_id == LDPC_HIP_BP_DEC && c->bp_chain) {
+            // Frames are decoded as if one after the other on ONE upstream DEC_STATE: frame b's input check sees the
+            // syndrome frame b-1 left behind, frame 0 the one the previous call left in this context.  A frame's final
+            // syndrome is non-zero exactly when it failed, and the stale syndrome only matters to the input check, so:
+            // pass 1 with zero stale syndromes (frame 0: the carry); then re-decode only the frames that follow a
+            // failed frame, with stale[b] = synd[b-1], and repeat for successors of frames whose outcome flipped.
+            // This entry point therefore synchronises the stream for BP_DEC (it reads the iteration counts back).
+            const size_t sw = (size_t)c->R / 32;
+            if (B > c->bp_frames) {
+                if (c->d_bp_stale) (void)hipFree(c->d_bp_stale);
+                if (c->d_bp_synd) (void)hipFree(c->d_bp_synd);
+                if (c->d_bp_idx) (void)hipFree(c->d_bp_idx);
+                c->d_bp_stale = nullptr; c->d_bp_synd = nullptr; c->d_bp_idx = nullptr; c->bp_frames = 0;
+                HIP_TRY(hipMalloc(&c->d_bp_stale, sizeof(uint32_t) * sw * (size_t)B));
+                HIP_TRY(hipMalloc(&c->d_bp_synd, sizeof(uint32_t) * sw * (size_t)B));
+                HIP_TRY(hipMalloc(&c->d_bp_idx, sizeof(int32_t) * (size_t)B));
+                c->bp_frames = B;
+            }
+            int32_t *own_iters = nullptr;   // the chain needs the iteration counts even if the caller does not
+            if (!d_iters) { HIP_TRY(hipMalloc(&own_iters, sizeof(int32_t) * (size_t)B)); sa.iters = own_iters; }
+            std::unique_ptr<int32_t, void (*)(int32_t *)> own_guard(own_iters, [](int32_t *p) { if (p) (void)hipFree(p); });
+            HIP_TRY(hipMemsetAsync(c->d_bp_stale, 0, sizeof(uint32_t) * sw * (size_t)B, stream));
+            HIP_TRY(hipMemcpyAsync(c->d_bp_stale, c->bp_carry.data(), sizeof(uint32_t) * sw, hipMemcpyHostToDevice, stream));
+            sa.stale = c->d_bp_stale; sa.synd_out = c->d_bp_synd; sa.frame_idx = nullptr;
+            if (int rc = launch(B)) return rc;
+            std::vector<int32_t> it_old((size_t)B), it_new((size_t)B), todo;
+            HIP_TRY(hipMemcpyAsync(it_old.data(), sa.iters, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (long long b = 1; b < B; ++b) if (it_old[b - 1] < 0) todo.push_back((int32_t)b);
+            while (!todo.empty()) {
+                if (B > 1) HIP_TRY(hipMemcpyAsync(c->d_bp_stale + sw, c->d_bp_synd, sizeof(uint32_t) * sw * (size_t)(B - 1), hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(c->d_bp_idx, todo.data(), sizeof(int32_t) * todo.size(), hipMemcpyHostToDevice, stream));
+                sa.frame_idx = c->d_bp_idx;
+                if (int rc = launch((long long)todo.size())) return rc;
+                HIP_TRY(hipMemcpyAsync(it_new.data(), sa.iters, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                std::vector<int32_t> next;
+                for (int32_t b : todo)
+                    if ((it_old[b] < 0) != (it_new[b] < 0) && b + 1 < B) next.push_back(b + 1);  // its successor saw the wrong stale syndrome
+                it_old = it_new;
+                todo.swap(next);
+            }
+            HIP_TRY(hipMemcpy(c->bp_carry.data(), c->d_bp_synd + sw * (size_t)(B - 1), sizeof(uint32_t) * sw, hipMemcpyDeviceToHost));
         } else {
-            HIP_TRY(hipModuleLaunchKernel(c->spec_jit->fn, (unsigned)B, 1, 1, (unsigned)c->spec_threads, 1, 1, (unsigned)c->spec_lds, stream,
-                                          kargs, nullptr));
+            if (int rc = launch(B)) return rc;
         }
     } else {
         ldpc::DecArgs a{};
@@ -475,7 +542,7 @@ int ldpc_hip_decode_host(ldpc_hip_ctx *c, double *llr, long long B, int maxiter,
     if (!c || !llr || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_decode_host: bad argument");
     if (B == 0) return 0;
     if (int rc = set_device(c)) return rc;
-    const bool sp = c->decoder_id == LDPC_HIP_SP_DEC;
+    const bool sp = c->decoder_id == LDPC_HIP_SP_DEC || c->decoder_id == LDPC_HIP_BP_DEC;  // soft[] is the working array upstream
     const bool tasp = c->decoder_id == LDPC_HIP_TASP_DEC || c->decoder_id == LDPC_HIP_ASP_DEC;  // probability-domain decoders
     if (c->decoder_id == LDPC_HIP_TASP_DEC) decision = 0;  // upstream ignores `decision` for this decoder: the result is always hard (decoders.cpp:2737-2738)
     const bool need_soft = decision != 0 || (sp && clobber_sp_input);
@@ -512,6 +579,13 @@ int ldpc_hip_decode_host(ldpc_hip_ctx *c, double *llr, long long B, int maxiter,
             llr[i] = e1 / (e0 + e1);
         }
     }
+    return 0;
+}
+
+int ldpc_hip_set_bp_chain(ldpc_hip_ctx *c, int on, int reset_carry) {
+    if (!c) return fail(LDPC_HIP_EINVAL, "ldpc_hip_set_bp_chain: null context");
+    c->bp_chain = on != 0;
+    if (reset_carry) std::fill(c->bp_carry.begin(), c->bp_carry.end(), 0u);
     return 0;
 }
 

@@ -108,7 +108,7 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
     static std::mutex mu;
     static std::map<std::string, Kernel> cache;
     const std::string code = code_struct(rows, nh, M);
-    const bool eight_waves = std::string(body) == "sp_body" || std::string(body) == "asp_body";  // 8 waves per frame, 2 frames per CU
+    const bool eight_waves = std::string(body) == "sp_body" || std::string(body) == "asp_body" || std::string(body) == "bp_body";  // 8 waves per frame, 2 frames per CU
     const int threads = eight_waves ? 512 : ((M + 63) / 64) * 64;
     const std::string key = std::to_string(device) + "|" + body + "|" + code;
     std::lock_guard<std::mutex> lk(mu);

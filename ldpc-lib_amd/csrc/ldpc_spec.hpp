@@ -34,6 +34,10 @@ struct SpecArgs {
     double *soft_out;    // [B][N] or null
     int maxiter;
     double alpha;
+    // bp_body only (the other bodies ignore these and decode frame blockIdx.x):
+    const u32 *stale;     // [B][R/32] syndrome the previous call left behind (upstream's DEC_STATE::syndr), or null = zeros
+    u32 *synd_out;        // [B][R/32] syndrome this call leaves behind, or null
+    const int *frame_idx; // [gridDim.x] frame decoded by each workgroup, or null = blockIdx.x
 };
 
 template <int I> struct IC { static constexpr int value = I; };
@@ -988,6 +992,171 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
     res = fail ? -steps : (steps == 0 ? 0 : steps);                           // 0: input codeword; steps+1 upstream == steps here
 
     if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
+    if (a.hard) {
+        for (int w = threadIdx.x; w < N / 32; w += T) {
+            u32 bits = 0;
+            for (int b = 0; b < 32; ++b) bits |= (u32)hb[32 * w + b] << b;
+            a.hard[fr * (N / 32) + w] = bits;
+        }
+    }
+    if (a.soft_out) {
+        static_for<0, NH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
+            if (wave == V.col_wave[u]) a.soft_out[fr * N + k * M + ch * 64 + lane] = so[q];
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gallager belief propagation in the log domain (upstream bp_decod_qc_lm, decoders.cpp:1708-1920, decoder id 0).
+// Work split of sp_body (8 waves per frame; block rows dealt round-robin, block columns dealt at compile time).
+// Per-edge message ZZ[e][t] (fp64) and sign BB[e][t] are indexed by VARIABLE position like upstream's ZZ[j][k*M+t].
+//   A  (column units)  A = exp(soft - ZZ); ZZ <- log|(A-1)/(A+1)|; BB <- A < 1                        (:1803-1812)
+//   A' (row units)     s[j][n] = sum of the row's ZZ at (n+c) mod M, columns ascending; bs = xor of BB  (:1815-1824)
+//   B  (column units)  soft = yd; rows ascending: A = exp(s - ZZ); ZZ <- clamp(+-log((1+A)/(1-A)), 19.07); soft += ZZ
+//   C  (row units)     syndrome of soft < 0
+// Upstream does not clear its syndrome array before the input check (:1742-1762), so that check sees the syndrome the
+// previous call on the same state left behind (non-zero after a failed frame): `stale` carries
+// it in, `synd_out` carries it out, and the host chains frames in order (ldpc_hip.hip).
+// exp()/log() are ocml's: hard decisions and iteration counts identical to the reference on all test sets (and
+// insensitive to +-1 ulp perturbations of every exp/log, tests/test_oracle_golden.py), soft values to tolerance.
+// ---------------------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void bp_body(const SpecArgs &a) {
+    static_assert(C::M % 64 == 0, "bp_body: lifting must be a multiple of 64");
+    constexpr SpView<C> V{};
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, R = RH * M, CH = M / 64, T = kSpWaves * 64;
+    constexpr int NE = V.ne, UMAX = V.units_max, RUMAX = (RH * CH + kSpWaves - 1) / kSpWaves;
+    extern __shared__ double lds[];
+    char *const zzb = reinterpret_cast<char *>(lds);                                  // ZZ[e][t] at e*M*8 + t*8
+    char *const sb = zzb + (size_t)NE * M * 8;                                        // s[j][n]
+    unsigned char *const bbb = reinterpret_cast<unsigned char *>(sb + (size_t)R * 8); // BB[e][t]
+    unsigned char *const bsb = bbb + (size_t)NE * M;                                  // bs[j][n]
+    unsigned char *const hb = bsb + R;                                                // [N] soft < 0
+    int *const flag = reinterpret_cast<int *>(hb + ((N + 15) & ~15));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long fr = a.frame_idx ? a.frame_idx[blockIdx.x] : (long long)blockIdx.x;
+
+    auto mind = [](double x, double y) { return x < y ? x : y; };            // decoders.cpp:104
+    auto maxd = [](double x, double y) { return x < y ? y : x; };            // decoders.cpp:105
+    auto vote = [&](bool fail) -> bool {
+        if (threadIdx.x == 0) *flag = 0;
+        __syncthreads();
+        if (__ballot(fail) != 0ull && lane == 0) atomicOr(flag, 1);
+        __syncthreads();
+        const bool r = *flag != 0;
+        __syncthreads();
+        return r;
+    };
+    u64 left[RUMAX];   // syndrome bits of this wave's row units as last computed (what upstream leaves in st->syndr)
+    static_for<0, RUMAX>([&](auto Q) { left[decltype(Q)::value] = 0ull; });
+    auto syndrome_fail = [&](bool with_stale) -> bool {
+        bool f = false;
+        static_for<0, RH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
+            if (wave == u % kSpWaves) {
+                const int n = ch * 64 + lane;
+                unsigned sy = 0;
+                if (with_stale && a.stale) sy = (a.stale[fr * (R / 32) + (j * M + n) / 32] >> (n & 31)) & 1u;
+                static_for<0, C::RW[j]>([&](auto S) {
+                    constexpr int s = decltype(S)::value;
+                    int t = n + C::SH[j][s]; if (t >= M) t -= M;
+                    sy ^= hb[C::COL[j][s] * M + t];
+                });
+                left[u / kSpWaves] = __ballot(sy != 0);
+                f |= sy != 0;
+            }
+        });
+        return f;
+    };
+
+    double yd[UMAX], so[UMAX];
+    static_for<0, UMAX>([&](auto Q) { yd[decltype(Q)::value] = 0.0; so[decltype(Q)::value] = 0.0; });
+    static_for<0, NH * CH>([&](auto U) {
+        constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
+        if (wave == V.col_wave[u]) {
+            const int t = ch * 64 + lane;
+            const double y = maxd(mind(a.llr[fr * N + k * M + t], 20.0), -20.0);   // :1738 INPUT_LIMIT
+            yd[q] = so[q] = y;
+            hb[k * M + t] = y < 0;
+            static_for<0, V.cw[k]>([&](auto X) {                                    // :1731-1733
+                *reinterpret_cast<double *>(zzb + (size_t)V.ce[k][decltype(X)::value] * M * 8 + t * 8) = 0.0;
+            });
+        }
+    });
+    __syncthreads();
+
+    bool fail = vote(syndrome_fail(true));                                          // :1742-1766
+    int iter = 0;
+    while (fail && iter < a.maxiter) {
+        // ---- A: variable-node activation
+        static_for<0, NH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
+            if (wave == V.col_wave[u]) {
+                const int t = ch * 64 + lane;
+                static_for<0, V.cw[k]>([&](auto X) {
+                    constexpr int e = V.ce[k][decltype(X)::value];
+                    double *z = reinterpret_cast<double *>(zzb + (size_t)e * M * 8 + t * 8);
+                    const double A = exp(so[q] - *z);
+                    *z = log(fabs((A - 1) / (A + 1)));
+                    bbb[e * M + t] = A < 1;
+                });
+            }
+        });
+        __syncthreads();
+        // ---- A': check sums
+        static_for<0, RH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
+            if (wave == u % kSpWaves) {
+                const int n = ch * 64 + lane;
+                double s = 0.0;
+                unsigned bs = 0;
+                static_for<0, C::RW[j]>([&](auto S) {
+                    constexpr int x = decltype(S)::value, e = V.row_off[j] + x;
+                    int t = n + C::SH[j][x]; if (t >= M) t -= M;
+                    s += *reinterpret_cast<const double *>(zzb + (size_t)e * M * 8 + t * 8);
+                    bs ^= bbb[e * M + t];
+                });
+                *reinterpret_cast<double *>(sb + (size_t)(j * M + n) * 8) = s;
+                bsb[j * M + n] = (unsigned char)bs;
+            }
+        });
+        __syncthreads();
+        // ---- B: check-node activation seen from the variable, a-posteriori sums
+        static_for<0, NH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
+            if (wave == V.col_wave[u]) {
+                const int t = ch * 64 + lane;
+                double soft = yd[q];                                                  // :1834
+                static_for<0, V.cw[k]>([&](auto X) {
+                    constexpr int x = decltype(X)::value, e = V.ce[k][x], j = V.cj[k][x];
+                    int nn = t - V.cc[k][x]; if (nn < 0) nn += M;                     // rotate by m - circ (:1847)
+                    double *z = reinterpret_cast<double *>(zzb + (size_t)e * M * 8 + t * 8);
+                    double A = exp(*reinterpret_cast<const double *>(sb + (size_t)(j * M + nn) * 8) - *z);
+                    const int b = bsb[j * M + nn] ^ bbb[e * M + t];
+                    A = (double)(1 - 2 * b) * log((1 + A) / (1 - A));
+                    const double zn = maxd(mind(A, 19.07), -19.07);
+                    *z = zn;
+                    soft += zn;
+                });
+                so[q] = soft;
+                hb[k * M + t] = soft < 0;
+            }
+        });
+        __syncthreads();
+        fail = vote(syndrome_fail(false));                                          // :1869-1893 (array cleared at :1788)
+        iter = iter + 1;
+    }
+    const int res = fail ? -iter : iter;
+
+    if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
+    if (a.synd_out) {
+        static_for<0, RH * CH>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            if (wave == u % kSpWaves && lane == 0) reinterpret_cast<u64 *>(a.synd_out + fr * (R / 32))[u] = left[u / kSpWaves];
+        });
+    }
     if (a.hard) {
         for (int w = threadIdx.x; w < N / 32; w += T) {
             u32 bits = 0;

@@ -59,7 +59,7 @@ extern "C" int orc_bp_simulation(int rh, int nh, const int *H, int M, int max_it
     int out_type;  // bp_simulation.cpp:451-466
     switch (decoder_type) {
     case 1: case 2: case 7: out_type = 1; break;    // SP_DEC, ASP_DEC, TASP_DEC
-    case 3: case 4: case 8: out_type = 0; break;  // MS, IMS, LMS
+    case 0: case 3: case 4: case 8: out_type = 0; break;  // BP, MS, IMS, LMS
     default: orc_close(code); return -4;
     }
 
@@ -94,6 +94,7 @@ extern "C" int orc_bp_simulation(int rh, int nh, const int *H, int M, int max_it
         case 1: iter = orc_sum_prod(code, y.data(), decword.data(), max_iterations, 0); break;
         case 3: iter = orc_min_sum(code, y.data(), decword.data(), max_iterations, 0, 0.8); break;
         case 4: iter = orc_imin_sum(code, y.data(), decword.data(), max_iterations, 0, 0.8, 1.4, 6, 8); break;
+        case 0: iter = orc_bp(code, y.data(), decword.data(), max_iterations, 0); break;
         case 2: iter = orc_sum_prod_gf2(code, y.data(), decword.data(), max_iterations, 0); break;
         case 7: iter = orc_tdmp_sum_prod(code, y.data(), decword.data(), max_iterations, nullptr); break;
         default: iter = orc_lmin_sum(code, y.data(), decword.data(), max_iterations, 0); break;

@@ -39,6 +39,9 @@ struct orc_code {
     double *yd, *s;  /* [N], [R] */
     double *ZZ;      /* [ne*M]  message of edge-block e at VARIABLE position t (reference: ZZ[j][k*M+t]) */
     double *ZZ0;     /* [rh*M] scratch: ZZ0[j][t] */
+    unsigned char *bp_BB;    /* [ne*M] */
+    unsigned char *bp_bs;    /* [R] */
+    unsigned char *bp_syndr; /* [R] PERSISTS between calls, like DEC_STATE::syndr */
     /* integer min-sum */
     short *isoft, *iy, *imin1, *imin2, *inmin1, *inmin2;
 };
@@ -97,6 +100,9 @@ orc_code *orc_open(int rh, int nh, int M, const short *hd) {
     c->s = (double *)calloc(c->R, sizeof(double));
     c->ZZ = (double *)calloc((size_t)(c->ne + 1) * M, sizeof(double));
     c->ZZ0 = (double *)calloc((size_t)rh * M, sizeof(double));
+    c->bp_BB = (unsigned char *)calloc((size_t)(c->ne + 1) * M, 1);
+    c->bp_bs = (unsigned char *)calloc(c->R, 1);
+    c->bp_syndr = (unsigned char *)calloc(c->R, 1);
     c->isoft = (short *)calloc(c->N, sizeof(short));
     c->iy = (short *)calloc(c->N, sizeof(short));
     c->imin1 = (short *)calloc(c->R, sizeof(short));
@@ -112,6 +118,7 @@ void orc_close(orc_code *c) {
     free(c->soft); free(c->min1); free(c->min2); free(c->pos); free(c->sgn);
     free(c->nmin1); free(c->nmin2); free(c->npos); free(c->nsgn); free(c->S); free(c->synd); free(c->tmp);
     free(c->yd); free(c->s); free(c->ZZ); free(c->ZZ0);
+    free(c->bp_BB); free(c->bp_bs); free(c->bp_syndr);
     free(c->isoft); free(c->iy); free(c->imin1); free(c->imin2); free(c->inmin1); free(c->inmin2);
     free(c);
 }
@@ -550,6 +557,89 @@ int orc_sum_prod_gf2(orc_code *c, double *soft, double *decword, int maxsteps, i
     }
     for (v = 0; v < N; v++) decword[v] = decision ? so[v] : (double)(so[v] > 0.5);
     return -steps;
+}
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Gallager belief propagation in the log domain: decoders.cpp:1708-1920 (BP_DEC, id 0; BP_USE_EPS is
+ * not defined, decoders.h:9).  ZZ[e][t] / BB[e][t] are indexed by VARIABLE position like upstream's
+ * ZZ[j][k*M+t].  The syndrome array is NOT cleared before the input check (:1742-1762): it still holds
+ * the final syndrome of the previous call on this state, which is non-zero after a failed frame
+ *  -- restated, with orc_bp_stale() to read / set that carried state.
+ * ------------------------------------------------------------------------------------------- */
+#ifndef ORC_BP_EXP
+#define ORC_BP_EXP exp
+#define ORC_BP_LOG log
+#endif
+unsigned char *orc_bp_stale(orc_code *c) { return c->bp_syndr; }
+
+int orc_bp(orc_code *c, double *soft, double *decword, int maxiter, int decision) {
+    const int M = c->M, N = c->N, R = c->R, nh = c->nh;
+    double *yd = c->yd, *s = c->s, *ZZ = c->ZZ;
+    unsigned char *BB = c->bp_BB, *bs = c->bp_bs, *sy = c->bp_syndr;
+    int v, e, n, i, q, iter = 0, synd;
+
+    memset(ZZ, 0, sizeof(double) * (size_t)c->ne * M);                          /* :1731-1733 */
+    for (v = 0; v < N; v++) yd[v] = soft[v] = orc_maxd(orc_mind(soft[v], 20.0), -20.0); /* :1737-1738 */
+    for (e = 0; e < c->ne; e++) {                                                /* :1742-1762, no memset first */
+        const double *col = soft + c->e_col[e] * M;
+        unsigned char *row = sy + c->e_row[e] * M;
+        for (n = 0; n < M; n++) row[n] ^= (col[ROT(n, c->e_shift[e], M)] < 0);
+    }
+    synd = 0;
+    for (n = 0; n < R; n++) synd |= sy[n];
+    if (!synd) {
+        for (v = 0; v < N; v++) decword[v] = decision ? soft[v] : (double)(soft[v] < 0);
+        return 0;
+    }
+    while (iter < maxiter) {
+        memset(sy, 0, R); memset(bs, 0, R); memset(s, 0, sizeof(double) * R);   /* :1788-1790 */
+        for (i = 0; i < nh; i++) {                                               /* :1792-1829 columns outer, rows inner */
+            for (q = c->col_start[i]; q < c->col_start[i + 1]; q++) {
+                const int ee = c->col_edge[q], j = c->e_row[ee], sh = c->e_shift[ee];
+                double *z = ZZ + (size_t)ee * M;
+                unsigned char *b = BB + (size_t)ee * M;
+                for (n = 0; n < M; n++) {
+                    const double A = ORC_BP_EXP(soft[i * M + n] - z[n]);
+                    const double x = ORC_BP_LOG(fabs((A - 1) / (A + 1)));
+                    b[n] = A < 1;
+                    z[n] = x;
+                }
+                for (n = 0; n < M; n++) {
+                    const int t = ROT(n, sh, M);
+                    s[j * M + n] += z[t];
+                    bs[j * M + n] ^= b[t];
+                }
+            }
+        }
+        memcpy(soft, yd, sizeof(double) * N);                                    /* :1834 */
+        for (i = 0; i < nh; i++) {                                               /* :1836-1866 */
+            for (q = c->col_start[i]; q < c->col_start[i + 1]; q++) {
+                const int ee = c->col_edge[q], j = c->e_row[ee], sh = c->e_shift[ee];
+                double *z = ZZ + (size_t)ee * M;
+                const unsigned char *b = BB + (size_t)ee * M;
+                for (n = 0; n < M; n++) {
+                    int nn = n - sh; if (nn < 0) nn += M;                         /* rotate by m - circ */
+                    double A = ORC_BP_EXP(s[j * M + nn] - z[n]);
+                    const int bb = bs[j * M + nn] ^ b[n];
+                    A = (1 - 2 * bb) * ORC_BP_LOG((1 + A) / (1 - A));
+                    z[n] = orc_maxd(orc_mind(A, 19.07), -19.07);
+                }
+                for (n = 0; n < M; n++) soft[i * M + n] += z[n];
+            }
+        }
+        for (e = 0; e < c->ne; e++) {                                            /* :1869-1887 (sy was cleared above) */
+            const double *col = soft + c->e_col[e] * M;
+            unsigned char *row = sy + c->e_row[e] * M;
+            for (n = 0; n < M; n++) row[n] ^= (col[ROT(n, c->e_shift[e], M)] < 0);
+        }
+        synd = 0;
+        for (n = 0; n < R; n++) synd |= sy[n];
+        iter++;
+        if (!synd) break;
+    }
+    for (v = 0; v < N; v++) decword[v] = decision ? soft[v] : (double)(soft[v] < 0);
+    return synd ? -iter : iter;                                                  /* :1901-1919 */
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -64,6 +64,13 @@ int orc_tdmp_sum_prod(orc_code *c, double *soft, double *decword, int maxsteps, 
  * or soft_out (decision != 0).  returns 0 / steps+1 / -steps. */
 int orc_sum_prod_gf2(orc_code *c, double *soft, double *decword, int maxsteps, int decision);
 
+/* decoders.cpp:1708-1920 bp_decod_qc_lm ("BP", decoder id 0): Gallager belief propagation in the log domain.
+ * soft[] is CLOBBERED (input clamp :1738, then the a-posteriori LLRs).  decword = soft < 0, or soft (decision != 0).
+ * returns 0 (input check passed) / iterations / -iterations.  The input check XORs into the syndrome the previous call
+ * on this state left behind: orc_bp_stale() exposes that carried [R] byte array. */
+int orc_bp(orc_code *c, double *soft, double *decword, int maxiter, int decision);
+unsigned char *orc_bp_stale(orc_code *c);
+
 /* Syndrome of hard decisions (soft<0) : decoders.cpp:793-814 check_syndrome. returns 1 if any check fails. */
 int orc_syndrome_nonzero(const orc_code *c, const double *soft);
 

@@ -17,7 +17,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from ldpc_testlib import (ASP_DEC, GOLDEN_DIR, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Reference, awgn_llr, load_base_matrix,  # noqa: E402
+from ldpc_testlib import (ASP_DEC, BP_DEC, GOLDEN_DIR, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Reference, awgn_llr, load_base_matrix,  # noqa: E402
                           oracle_lib, pack_bits, ref_lib, relift, _as_double_p)
 
 SETS = [
@@ -45,6 +45,10 @@ SETS = [
     ("asp_m64_2p0",    ASP_DEC, 64,  2.0, 24, 50, 4),   # probability-domain flooding sum-product (decoder 2)
     ("asp_m64_1p2",    ASP_DEC, 64,  1.2, 12, 50, 2),
     ("asp_m128_1p7",   ASP_DEC, 128, 1.7, 8,  30, 2),
+    ("bp_m64_2p0",     BP_DEC,  64,  2.0, 24, 50, 4),   # Gallager BP in the log domain (decoder 0)
+    ("bp_m64_1p0_stale", BP_DEC, 64, 1.0, 16, 50, 2),   # failed frames followed by frames that are codewords at the input:
+                                                        # upstream's uncleared syndrome array makes those return 1, not 0 (Q8)
+    ("bp_m128_1p7",    BP_DEC,  128, 1.7, 8,  30, 2),
 ]
 ONLY = set(sys.argv[1:])  # optional: regenerate just the named sets
 
@@ -59,6 +63,10 @@ def main():
             continue
         H = relift(H0, M)
         llr = awgn_llr(H, M, snr, 1, frames)
+        if name.endswith("_stale"):
+            clean = awgn_llr(H, M, 15.0, 2, frames)   # no channel errors: codewords at the decoder input
+            for f in (0, 2, 6, 9, 10):               # 2, 6, 9 follow failed frames; 0 and 10 do not
+                llr[f] = clean[f]
         ref = Reference(dec, H, M)
         dec0, it0, after0 = ref.decode(dec, llr, maxiter, 0)
         dec1, it1, _ = ref.decode(dec, llr[:soft_frames], maxiter, 1)

@@ -37,6 +37,7 @@ int main(int argc, char **argv) {
         switch (dec_id) {                                               // bp_simulation.cpp:716-729
         case SP_DEC: it = sum_prod_decod_qc_lm(st, st->y, st->decword, maxiter, decision); break;
         case MS_DEC: it = min_sum_decod_qc_lm(st, st->y, st->decword, maxiter, decision, MS_ALPHA); break;
+        case BP_DEC: it = bp_decod_qc_lm(st, st->y, st->decword, maxiter, decision); break;
         case ASP_DEC: it = sum_prod_gf2_decod_qc_lm(st, st->y, st->decword, maxiter, decision); break;
         case TASP_DEC: it = tdmp_sum_prod_gf2_decod_qc_lm(st, st->y, st->decword, maxiter, decision); break;
         case IMS_DEC: it = imin_sum_decod_qc_lm(st, st->y, st->decword, maxiter, decision, MS_ALPHA, MS_THR, MS_QBITS, MS_DBITS); break;
@@ -51,7 +52,7 @@ int main(int argc, char **argv) {
     std::vector<int> it2(B);
     ldpc_decod_batch(st, llr2.data(), dec2.data(), it2.data(), B, maxiter, decision);
     if (memcmp(it2.data(), iters.data(), sizeof(int) * B) != 0) return 20;
-    if (dec_id != SP_DEC && dec_id != TASP_DEC && dec_id != ASP_DEC && memcmp(dec2.data(), dec.data(), sizeof(double) * dec.size()) != 0) return 21;
+    if (dec_id != BP_DEC && dec_id != SP_DEC && dec_id != TASP_DEC && dec_id != ASP_DEC && memcmp(dec2.data(), dec.data(), sizeof(double) * dec.size()) != 0) return 21;
     decod_close(st);
 
     f = fopen(argv[2], "wb");

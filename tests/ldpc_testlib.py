@@ -72,6 +72,9 @@ def oracle_lib():
     lib.orc_sum_prod.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int]
     lib.orc_imin_sum.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
     lib.orc_sum_prod_gf2.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int]
+    lib.orc_bp.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int]
+    lib.orc_bp_stale.argtypes = [C.c_void_p]
+    lib.orc_bp_stale.restype = C.POINTER(C.c_ubyte)
     lib.orc_tdmp_sum_prod.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int, c_double_p]
     lib.orc_syndrome_nonzero.argtypes = [C.c_void_p, c_double_p]
     lib.orc_qam_modulate.argtypes = [C.c_int, c_double_p, C.c_int, c_double_p]
@@ -151,6 +154,8 @@ class Oracle(_Decoder):
             return self.lib.orc_sum_prod(self.h, yp, dp, maxiter, decision)
         if dec_id == IMS_DEC:
             return self.lib.orc_imin_sum(self.h, yp, dp, maxiter, decision, 0.8, 1.4, 6, 8)
+        if dec_id == BP_DEC:
+            return self.lib.orc_bp(self.h, yp, dp, maxiter, decision)
         if dec_id == ASP_DEC:
             return self.lib.orc_sum_prod_gf2(self.h, yp, dp, maxiter, decision)
         if dec_id == TASP_DEC:  # decision is dead upstream: decword is always hard; decision=1 here returns the posteriors

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from ldpc_testlib import (ASP_DEC, GOLDEN_DIR, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Oracle, awgn_llr, bpsk_sigma, load_base_matrix, pack_bits,
+from ldpc_testlib import (ASP_DEC, BP_DEC, GOLDEN_DIR, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Oracle, awgn_llr, bpsk_sigma, load_base_matrix, pack_bits,
                           philox_gauss_pairs, relift, syndrome_np, unpack_bits)
 
 pytestmark = pytest.mark.gpu
@@ -24,6 +24,10 @@ SP_RTOL = 1e-6
 # frames that do not converge (the layered probability-domain recursion is chaotic there); converged frames agree to
 # ~1e-12.  STATED TOLERANCE for TASP a-posteriori probabilities: relative 1e-4.  Hard decisions and step counts identical.
 TASP_RTOL = 1e-4
+# Gallager BP in the log domain (BP): 2 exp + 2 log per edge and iteration on the device (ocml) vs glibc.  Hard decisions and
+# iteration counts identical on all test sets (and provably insensitive to +-1 ulp on every exp/log on 700 frames, see
+# tests/test_oracle_golden.py::test_bp_outputs_survive_one_ulp_perturbations).  STATED TOLERANCE for a-posteriori LLRs:
+BP_RTOL, BP_ATOL = 1e-5, 1e-7
 
 
 @pytest.fixture(scope="module")
@@ -52,6 +56,8 @@ def test_golden_vectors_host_api(L, name):
         assert np.array_equal(it1, g["iters"][:ns])
         if dec_id == SP_DEC:
             np.testing.assert_allclose(d1, g["soft"], rtol=SP_RTOL, atol=0)
+        elif dec_id == BP_DEC:
+            np.testing.assert_allclose(d1, g["soft"], rtol=BP_RTOL, atol=BP_ATOL)   # a-posteriori LLRs
         elif dec_id == ASP_DEC:
             np.testing.assert_allclose(d1, g["soft"], rtol=TASP_RTOL, atol=0)   # a-posteriori P(bit=1)
             x = np.clip(g["llr"] * 0.5, -20.0, 20.0)  # the input is left holding the channel P(bit=1) (decoders.cpp:2351-2358)
@@ -85,6 +91,8 @@ def test_golden_vectors_host_api(L, name):
     (TASP_DEC, 200, (1.6,), 10, 15),            # hiprtc instance, 4 waves per frame
     (ASP_DEC, 64, (1.0, 1.6, 2.2), 120, 30),    # probability-domain flooding sum-product (decoder 2), ahead-of-time instance
     (ASP_DEC, 128, (1.7,), 20, 25),             # hiprtc instance, two 64-lane chunks per block row/column
+    (BP_DEC, 64, (1.0, 1.6, 2.2), 120, 30),     # Gallager BP (decoder 0), ahead-of-time instance; failed frames chain into successors
+    (BP_DEC, 128, (1.7,), 20, 25),              # hiprtc instance
 ])
 def test_random_batches_against_oracle(L, torch, dec_id, M, snrs, frames, maxiter):
     H = relift(load_base_matrix(), M)
@@ -98,8 +106,10 @@ def test_random_batches_against_oracle(L, torch, dec_id, M, snrs, frames, maxite
         assert np.array_equal(iters.cpu().numpy(), it_ref)
         assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
         assert np.array_equal(x.cpu().numpy(), llr)  # the device entry point never modifies its input
-        s_ref, _, _ = o.decode(dec_id, llr, maxiter, 1)
-        if dec_id in (SP_DEC, ASP_DEC, TASP_DEC):  # exp() on the device vs glibc: a-posteriori values to the stated tolerance
+        s_ref, _, _ = (Oracle(H, M) if dec_id == BP_DEC else o).decode(dec_id, llr, maxiter, 1)  # BP: state carries between calls
+        if dec_id == BP_DEC:
+            np.testing.assert_allclose(soft.cpu().numpy(), s_ref, rtol=BP_RTOL, atol=BP_ATOL)
+        elif dec_id in (SP_DEC, ASP_DEC, TASP_DEC):  # exp() on the device vs glibc: a-posteriori values to the stated tolerance
             np.testing.assert_allclose(soft.cpu().numpy(), s_ref, rtol=SP_RTOL if dec_id == SP_DEC else TASP_RTOL)
         else:
             assert np.array_equal(soft.cpu().numpy(), s_ref)
@@ -338,6 +348,7 @@ def _compat_lib(L):
     (MS_DEC, 64, 3.0, 50, 10**9, 200, 1.0, 0, 2, 5),        # two punctured blocks (:697-710)
     (TASP_DEC, 126, 1.7, 15, 50, 10**8, 1.0, 0, 0, 1),      # the shipped `search` scenario: 50 errored frames in 821
     (ASP_DEC, 64, 1.6, 30, 10**9, 250, 1.0, 0, 0, 2),       # probability-domain sum-product, out_type 1 puncturing value
+    (BP_DEC, 64, 1.3, 30, 10**9, 250, 1.0, 0, 0, 2),        # Gallager BP: failed frames leave their syndrome to the next frame
 ])
 def test_exact_replay_harness_equals_the_sequential_harness(L, dec_id, M, snr, maxit, n_fe, n_exp, ref, mod, punct, seed):
     """C++ bp_simulation on the GPU (batched, host mt19937 noise in upstream's draw order) == the sequential CPU
@@ -364,7 +375,7 @@ def test_exact_replay_harness_equals_the_sequential_harness(L, dec_id, M, snr, m
 
 
 @pytest.mark.parametrize("name", ["ms_m64_1p2", "lms_m64_0p8", "sp_m64_2p0", "ms_m126_1p7", "ms_m1_4p0", "ims_m64_2p0", "tasp_m126_1p7",
-                                  "asp_m64_1p2"])
+                                  "asp_m64_1p2", "bp_m64_1p0_stale"])
 def test_decoders_h_call_surface(L, tmp_path, name):
     """decod_open / hd fill / decod_init / <decoder>(st, st->y, st->decword, ...) / decod_close from a C++ program built
     against include/ldpc/decoders.h, on the reference's golden vectors."""
@@ -393,14 +404,35 @@ def test_decoders_h_call_surface(L, tmp_path, name):
         assert np.array_equal(iters, g["iters"][:nfr])
         if decision == 0 or dec_id == TASP_DEC:
             assert np.array_equal(pack_bits(dec), g["hard"][:nfr])
+        elif dec_id == BP_DEC:
+            np.testing.assert_allclose(dec, g["soft"], rtol=BP_RTOL, atol=BP_ATOL)
         elif dec_id in (SP_DEC, ASP_DEC):
             np.testing.assert_allclose(dec, g["soft"], rtol=SP_RTOL if dec_id == SP_DEC else TASP_RTOL)
         else:
             assert np.array_equal(dec, g["soft"])
-        if dec_id not in (SP_DEC, ASP_DEC, TASP_DEC):
+        if dec_id not in (BP_DEC, SP_DEC, ASP_DEC, TASP_DEC):
             assert np.array_equal(after, llr)          # MS/LMS leave y intact (SURVEY 8b ownership)
         else:
             assert not np.array_equal(after, llr)      # SP clobbers its input like upstream (decoders.cpp:1950)
+
+
+def test_bp_frames_chain_through_the_uncleared_syndrome(L):
+    """Upstream's bp_decod_qc_lm XORs its input check into the syndrome the previous call left behind (decoders.cpp:1742-1762,
+    SURVEY Appendix B Q8): a codeword-at-the-input frame that follows a FAILED frame returns 1, not 0.  The golden set holds
+    such frames (2, 6, 9) and controls (0, 10).  The chain must survive any split into calls, and switch off cleanly."""
+    g = np.load(os.path.join(GOLDEN_DIR, "bp_m64_1p0_stale.npz"))
+    H, M, maxiter, llr, want = g["H"], int(g["M"]), int(g["maxiter"]), g["llr"], g["iters"]
+    assert [int(want[f]) for f in (0, 1, 2, 5, 6, 8, 9, 10)] == [0, -50, 1, -50, 1, -50, 1, 0]
+    with L.LdpcHip(BP_DEC, H, M) as dec:
+        parts = [dec.decode_host(llr[a:b], maxiter)[1] for a, b in ((0, 2), (2, 3), (3, 9), (9, 16))]   # every cut after a failed frame
+        assert np.array_equal(np.concatenate(parts), want)
+        dec.set_bp_chain(True, reset_carry=True)
+        d, it, _ = dec.decode_host(llr, maxiter)
+        assert np.array_equal(it, want) and np.array_equal(pack_bits(d), g["hard"])
+        dec.set_bp_chain(False, reset_carry=True)     # every frame from a zero syndrome: only the chained frames change
+        _, it0, _ = dec.decode_host(llr, maxiter)
+        changed = np.nonzero(it0 != want)[0].tolist()
+        assert changed == [2, 6, 9] and all(it0[f] == 0 for f in changed)
 
 
 @pytest.mark.parametrize("M,frames", [(64, 96), (126, 24), (200, 12), (512, 6)])

@@ -3,7 +3,7 @@ random batches beyond the committed goldens.  Skipped wherever oracle/_ref was n
 import numpy as np
 import pytest
 
-from ldpc_testlib import (ASP_DEC, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Oracle, Reference, awgn_llr, load_base_matrix, ref_lib,
+from ldpc_testlib import (ASP_DEC, BP_DEC, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Oracle, Reference, awgn_llr, load_base_matrix, ref_lib,
                           relift)
 
 pytestmark = pytest.mark.skipif(ref_lib() is None, reason="oracle/_ref not built (needs the upstream tree)")
@@ -13,6 +13,7 @@ pytestmark = pytest.mark.skipif(ref_lib() is None, reason="oracle/_ref not built
     (MS_DEC, 64, 1.5, 60, 50, 11), (MS_DEC, 64, 2.5, 60, 10, 12), (MS_DEC, 7, 3.0, 60, 30, 13),
     (MS_DEC, 126, 1.7, 12, 50, 14), (LMS_DEC, 64, 1.2, 40, 50, 15), (LMS_DEC, 200, 1.4, 8, 50, 16),
     (SP_DEC, 64, 1.5, 40, 50, 17), (SP_DEC, 33, 2.0, 30, 25, 18), (IMS_DEC, 64, 2.2, 30, 50, 19),
+    (BP_DEC, 64, 1.3, 40, 40, 33), (BP_DEC, 126, 1.7, 8, 30, 34), (BP_DEC, 1, 4.0, 300, 20, 35), (BP_DEC, 5, 2.0, 60, 30, 36),
     (ASP_DEC, 64, 1.4, 30, 40, 30), (ASP_DEC, 126, 1.7, 8, 30, 31), (ASP_DEC, 5, 3.0, 40, 30, 32),
     (TASP_DEC, 64, 1.5, 40, 15, 20), (TASP_DEC, 126, 1.7, 10, 15, 21), (TASP_DEC, 9, 3.0, 40, 30, 22),
 ])
