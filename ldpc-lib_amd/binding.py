@@ -233,7 +233,7 @@ def qam_demod(x, Q, T, sigma, out_type=0, device=0, stream=None):
     """Function-level soft demapper (QAM_demodulator.cpp Demodulate) on a CUDA float64 tensor x[ns,2] -> [ns, log2 Q]."""
     import torch
     lib = load_library()
-    m = {4: 2, 16: 4}[Q]
+    m = {4: 2, 16: 4, 64: 6, 256: 8}[Q]
     ns = x.shape[0]
     out = torch.empty((ns, m), dtype=torch.float64, device=x.device)
     rc = lib.ldpc_hip_qam_demod_dev(Q, float(T), float(sigma), x.data_ptr(), ns, out.data_ptr(), out_type, device, _stream_ptr(stream))

@@ -2,7 +2,7 @@
 //
 //   awgn_llr_kernel        bp_simulation.cpp:444-449,600-612,697-710  (BPSK / QAM4 LLRs of the all-zero codeword)
 //   awgn_qam16_llr_kernel  QAM_modulator.cpp:142 + bp_simulation.cpp:621-628 (as intended) + QAM_demodulator.cpp:203-275
-//   qam_demod_kernel       QAM_demodulator.cpp:99-566 Demodulate(), Q in {4,16}
+//   qam_demod_kernel       QAM_demodulator.cpp:99-566 Demodulate(), Q in {4,16,64,256}
 //   count_errors_kernel    bp_simulation.cpp:731-759,805-810
 //
 // These are streaming, HBM-bound byte/word kernels: one element (pair) per lane, coalesced 8/16-byte accesses,
@@ -108,20 +108,46 @@ __device__ __forceinline__ double llr_or_p(double p0, double p1, double T, int o
     return out_type == 0 ? log(p1 / p0) : p1;
 }
 
-__device__ __forceinline__ void demod_rail16(double x, double N0, double T, int out_type, double &b0, double &b1) {
-    double P[4], sum = 0;
+// One PAM rail of H bits (SQ = 2^H levels 2i - (SQ-1), anti-Gray labelled): posterior level probabilities with the
+// exp cut-off T, then per bit the two partition sums in the reference's association order
+// (QAM_demodulator.cpp:203-275 H = 2, :276-393 H = 3, :395-561 H = 4).
+template <int H>
+__device__ __forceinline__ void demod_rail(double x, double N0, double T, int out_type, double (&b)[H]) {
+    constexpr int SQ = 1 << H;
+    double P[SQ], sum = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        double t = x - (double)(2 * i - 3);
+    for (int i = 0; i < SQ; ++i) {
+        double t = x - (double)(2 * i - (SQ - 1));
         t *= t;
         t /= N0;
         P[i] = (t < T) ? exp(-t) : 0.0;
         sum += P[i];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) P[i] /= sum;
-    b0 = llr_or_p(P[0] + P[1], P[2] + P[3], T, out_type);
-    b1 = llr_or_p(P[0] + P[3], P[1] + P[2], T, out_type);
+    for (int i = 0; i < SQ; ++i) P[i] /= sum;
+    if constexpr (H == 2) {
+        b[0] = llr_or_p(P[0] + P[1], P[2] + P[3], T, out_type);
+        b[1] = llr_or_p(P[0] + P[3], P[1] + P[2], T, out_type);
+    } else if constexpr (H == 3) {
+        const double p12 = P[0] + P[1], p34 = P[2] + P[3], p56 = P[4] + P[5], p78 = P[6] + P[7];
+        b[0] = llr_or_p(p12 + p34, p56 + p78, T, out_type);
+        b[1] = llr_or_p(p12 + p78, p34 + p56, T, out_type);
+        b[2] = llr_or_p(P[0] + P[3] + P[4] + P[7], P[1] + P[2] + P[5] + P[6], T, out_type);
+    } else {
+        const double p12 = P[0] + P[1], p34 = P[2] + P[3], p56 = P[4] + P[5], p78 = P[6] + P[7];
+        const double p9A = P[8] + P[9], pBC = P[10] + P[11], pDE = P[12] + P[13], pFG = P[14] + P[15];
+        const double p1234 = p12 + p34, p5678 = p56 + p78, p9ABC = p9A + pBC, pDEFG = pDE + pFG;
+        b[0] = llr_or_p(p1234 + p5678, p9ABC + pDEFG, T, out_type);
+        b[1] = llr_or_p(p1234 + pDEFG, p5678 + p9ABC, T, out_type);
+        b[2] = llr_or_p(p12 + p78 + p9A + pFG, p34 + p56 + pBC + pDE, T, out_type);
+        b[3] = llr_or_p(P[0] + P[3] + P[4] + P[7] + P[8] + P[11] + P[12] + P[15],
+                        P[1] + P[2] + P[5] + P[6] + P[9] + P[10] + P[13] + P[14], T, out_type);
+    }
+}
+__device__ __forceinline__ void demod_rail16(double x, double N0, double T, int out_type, double &b0, double &b1) {
+    double b[2];
+    demod_rail<2>(x, N0, T, out_type, b);
+    b0 = b[0]; b1 = b[1];
 }
 
 struct DemodArgs {
@@ -141,12 +167,29 @@ __global__ void __launch_bounds__(256) qam_demod_kernel(const DemodArgs a) {
             const double sigma2 = a.sigma * a.sigma;
             a.out[2 * s] = 2.0 * xy.x / sigma2;
             a.out[2 * s + 1] = 2.0 * xy.y / sigma2;
-        } else {
+        } else if (a.Q == 16) {
             double b0, b1, b2, b3;
             demod_rail16(xy.x, N0, a.T, a.out_type, b0, b1);
             demod_rail16(xy.y, N0, a.T, a.out_type, b2, b3);
             *reinterpret_cast<double2 *>(a.out + 4 * s) = make_double2(b0, b1);
             *reinterpret_cast<double2 *>(a.out + 4 * s + 2) = make_double2(b2, b3);
+        } else if (a.Q == 64) {
+            double bi[3], bq[3];
+            demod_rail<3>(xy.x, N0, a.T, a.out_type, bi);
+            demod_rail<3>(xy.y, N0, a.T, a.out_type, bq);
+            double *o = a.out + 6 * s;
+            *reinterpret_cast<double2 *>(o) = make_double2(bi[0], bi[1]);
+            *reinterpret_cast<double2 *>(o + 2) = make_double2(bi[2], bq[0]);
+            *reinterpret_cast<double2 *>(o + 4) = make_double2(bq[1], bq[2]);
+        } else {
+            double bi[4], bq[4];
+            demod_rail<4>(xy.x, N0, a.T, a.out_type, bi);
+            demod_rail<4>(xy.y, N0, a.T, a.out_type, bq);
+            double *o = a.out + 8 * s;
+            *reinterpret_cast<double2 *>(o) = make_double2(bi[0], bi[1]);
+            *reinterpret_cast<double2 *>(o + 2) = make_double2(bi[2], bi[3]);
+            *reinterpret_cast<double2 *>(o + 4) = make_double2(bq[0], bq[1]);
+            *reinterpret_cast<double2 *>(o + 6) = make_double2(bq[2], bq[3]);
         }
     }
 }

@@ -645,7 +645,7 @@ int ldpc_hip_awgn_qam16_llr_dev(ldpc_hip_ctx *c, double snr_db, double T, uint64
 int ldpc_hip_qam_demod_dev(int Q, double T, double sigma, const double *d_x, long long ns, double *d_out,
                            int out_type, int device, void *stream_) {
     if (!d_x || !d_out || ns < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_qam_demod_dev: bad argument");
-    if (Q != 4 && Q != 16) return fail(LDPC_HIP_EUNSUPPORTED, "QAM-%d demapper not built (4, 16)", Q);
+    if (Q != 4 && Q != 16 && Q != 64 && Q != 256) return fail(LDPC_HIP_EUNSUPPORTED, "QAM-%d demapper not built (4, 16, 64, 256)", Q);
     if (Q == 4 && out_type != 0) return fail(LDPC_HIP_EUNSUPPORTED, "QAM-4 probability output not built");
     if (ns == 0) return 0;
     HIP_TRY(hipSetDevice(device));

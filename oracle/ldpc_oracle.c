@@ -806,6 +806,22 @@ void orc_qam_demodulate(int Q, double T, double sigma, const double *x, int ns, 
                 if (m == 4) {                     /* :203-275: levels ordered 00 01 11 10 */
                     out[sym * m + hh++] = orc_llr_or_p(P[0] + P[1], P[2] + P[3], T, out_type);
                     out[sym * m + hh++] = orc_llr_or_p(P[0] + P[3], P[1] + P[2], T, out_type);
+                } else if (m == 6) {              /* :276-393 QAM-64, sums in the reference's association order */
+                    const double p12 = P[0] + P[1], p34 = P[2] + P[3], p56 = P[4] + P[5], p78 = P[6] + P[7];
+                    const double p1234 = p12 + p34, p5678 = p56 + p78, p1278 = p12 + p78, p3456 = p34 + p56;
+                    out[sym * m + hh++] = orc_llr_or_p(p1234, p5678, T, out_type);
+                    out[sym * m + hh++] = orc_llr_or_p(p1278, p3456, T, out_type);
+                    out[sym * m + hh++] = orc_llr_or_p(P[0] + P[3] + P[4] + P[7], P[1] + P[2] + P[5] + P[6], T, out_type);
+                } else if (m == 8) {              /* :395-561 QAM-256 */
+                    const double p12 = P[0] + P[1], p34 = P[2] + P[3], p56 = P[4] + P[5], p78 = P[6] + P[7];
+                    const double p9A = P[8] + P[9], pBC = P[10] + P[11], pDE = P[12] + P[13], pFG = P[14] + P[15];
+                    const double p1234 = p12 + p34, p5678 = p56 + p78, p9ABC = p9A + pBC, pDEFG = pDE + pFG;
+                    const double p1to8 = p1234 + p5678, p9toG = p9ABC + pDEFG;
+                    out[sym * m + hh++] = orc_llr_or_p(p1to8, p9toG, T, out_type);
+                    out[sym * m + hh++] = orc_llr_or_p(p1234 + pDEFG, p5678 + p9ABC, T, out_type);
+                    out[sym * m + hh++] = orc_llr_or_p(p12 + p78 + p9A + pFG, p34 + p56 + pBC + pDE, T, out_type);
+                    out[sym * m + hh++] = orc_llr_or_p(P[0] + P[3] + P[4] + P[7] + P[8] + P[11] + P[12] + P[15],
+                                                       P[1] + P[2] + P[5] + P[6] + P[9] + P[10] + P[13] + P[14], T, out_type);
                 }
             }
         }

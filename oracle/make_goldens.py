@@ -79,13 +79,13 @@ def main():
         print(f"{name}: frames={frames} iters={it0.tolist()[:12]}... fail={(it0 < 0).sum()} errbits={int((dec0 != 0).sum())}")
         ref.close()
 
-    if ONLY:
+    if ONLY and "qam_frontend" not in ONLY:
         return
     # QAM front end (QAM_modulator.cpp / QAM_demodulator.cpp), function level.
     rlib = ref_lib()
     rng = np.random.RandomState(7)
     out = {}
-    for Q, m in ((4, 2), (16, 4)):
+    for Q, m in ((4, 2), (16, 4), (64, 6), (256, 8)):
         nbits = 64 * m
         bits = rng.randint(0, 2, nbits).astype(np.float64)
         sym = np.zeros(2 * (nbits // m), dtype=np.float64)

@@ -50,6 +50,13 @@ int main(int argc, char **argv) {
     // the batched extension must agree with the per-frame calls
     std::vector<double> llr2 = llr, dec2((size_t)B * N);
     std::vector<int> it2(B);
+    if (dec_id == BP_DEC) {   // BP carries the last frame's syndrome in the state (decoders.cpp:1742-1762): start over like the loop above did
+        decod_close(st);
+        st = decod_open(dec_id, 1, rh, nh, M);
+        if (!st) return 14;
+        for (int i = 0; i < rh; i++) for (int j = 0; j < nh; j++) st->hd[i][j] = hd[(size_t)i * nh + j];
+        if (!decod_init(st)) return 15;
+    }
     ldpc_decod_batch(st, llr2.data(), dec2.data(), it2.data(), B, maxiter, decision);
     if (memcmp(it2.data(), iters.data(), sizeof(int) * B) != 0) return 20;
     if (dec_id != BP_DEC && dec_id != SP_DEC && dec_id != TASP_DEC && dec_id != ASP_DEC && memcmp(dec2.data(), dec.data(), sizeof(double) * dec.size()) != 0) return 21;

@@ -271,15 +271,16 @@ def test_host_bp_simulation_replays_the_sequential_rule(L, torch):
 def test_qam_frontend(L, torch):
     from ldpc_lib_amd.binding import qam_demod
     g = np.load(os.path.join(GOLDEN_DIR, "qam_frontend.npz"))
-    for out_type in (0, 1):
-        for s in ("0p35", "0p8", "2p5"):
-            key = f"q16_t{out_type}_s{s}"
-            x = torch.from_numpy(g[key + "_x"].reshape(-1, 2)).cuda()
-            out = qam_demod(x, 16, 26.0, float(s.replace("p", ".")), out_type).cpu().numpy().ravel()
-            ref = g[key + "_llr"]
-            nan = np.isnan(ref)
-            assert np.array_equal(np.isnan(out), nan)
-            np.testing.assert_allclose(out[~nan], ref[~nan], rtol=1e-12, atol=1e-13)
+    for Q in (16, 64, 256):
+        for out_type in (0, 1):
+            for s in ("0p35", "0p8", "2p5"):
+                key = f"q{Q}_t{out_type}_s{s}"
+                x = torch.from_numpy(g[key + "_x"].reshape(-1, 2)).cuda()
+                out = qam_demod(x, Q, 26.0, float(s.replace("p", ".")), out_type).cpu().numpy().ravel()
+                ref = g[key + "_llr"]
+                nan = np.isnan(ref)
+                assert np.array_equal(np.isnan(out), nan), key
+                np.testing.assert_allclose(out[~nan], ref[~nan], rtol=1e-12, atol=1e-13, err_msg=key)
     key = "q4_t0_s0p8"
     x = torch.from_numpy(g[key + "_x"].reshape(-1, 2)).cuda()
     out = qam_demod(x, 4, 26.0, 0.8, 0).cpu().numpy().ravel()

@@ -41,7 +41,7 @@ def test_oracle_matches_reference_golden(name):
 def test_qam_frontend_matches_reference_golden():
     g = np.load(os.path.join(GOLDEN_DIR, "qam_frontend.npz"))
     lib = oracle_lib()
-    for Q, m in ((4, 2), (16, 4)):
+    for Q, m in ((4, 2), (16, 4), (64, 6), (256, 8)):
         bits = np.ascontiguousarray(g[f"q{Q}_bits"])
         sym = np.zeros(2 * (bits.size // m))
         ns = lib.orc_qam_modulate(Q, _as_double_p(bits), bits.size, _as_double_p(sym))

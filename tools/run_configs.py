@@ -56,6 +56,7 @@ out = [
     measure("f2 shipped search scenario: (4032,2016) M=126 TDMP sum-product (decoder 7) 15 it, 1.7 dB", L.DEC_TASP, 126, 1.7, 32768, 15),
     measure("f2 (2048,1024) TDMP sum-product 15 it", L.DEC_TASP, 64, 1.7, 65536, 15),
     measure("f2 (2048,1024) probability-domain flooding sum-product (decoder 2) 50 it", L.DEC_ASP, 64, 2.0, 32768, 50),
+    measure("f2 (2048,1024) Gallager BP, log domain (decoder 0) 50 it, frames chained", L.DEC_BP, 64, 2.0, 32768, 50),
 ]
 # front-end kernels alone
 with L.LdpcHip(L.DEC_MS, L.relift_base_matrix(H0, 64), 64) as dec:
