@@ -74,6 +74,8 @@ def load_library():
     for f in ("ldpc_hip_n", "ldpc_hip_r", "ldpc_hip_edges", "ldpc_hip_hard_words"):
         getattr(lib, f).argtypes = [vp]
     lib.ldpc_hip_kernel_name.argtypes = [vp]
+    lib.ldpc_hip_last_launch.argtypes = [vp]
+    lib.ldpc_hip_last_launch.restype = C.c_char_p
     lib.ldpc_hip_kernel_name.restype = C.c_char_p
     lib.ldpc_hip_decode_dev.argtypes = [vp, vp, i64, i32, f64, vp, vp, vp, vp]
     lib.ldpc_hip_decode_host.argtypes = [vp, vp, i64, i32, i32, f64, vp, vp, i32]
@@ -83,6 +85,7 @@ def load_library():
     lib.ldpc_hip_count_errors_dev.argtypes = [vp, vp, vp, i64, vp, vp, vp]
     lib.ldpc_hip_simulate.argtypes = [vp, f64, i32, i32, i32, f64, u64, i64, i64, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.ldpc_hip_set_bp_chain.argtypes = [vp, i32, i32]
+    lib.ldpc_hip_set_ims_params.argtypes = [vp, f64, i32, i32]
     lib.ldpc_hip_profile_enable.argtypes = [vp, i32]
     lib.ldpc_hip_profile_read.argtypes = [vp, C.POINTER(f64), C.POINTER(i64), i32]
     if lib.ldpc_hip_abi_version() != 1:
@@ -125,6 +128,13 @@ class LdpcHip:
         if getattr(self, "h", None):
             self.lib.ldpc_hip_close(self.h)
             self.h = None
+
+    def last_launch(self):
+        return self.lib.ldpc_hip_last_launch(self.h).decode()
+
+    def set_ims_params(self, thr=1.4, qbits=6, dbits=8):
+        """IMS_DEC: the quantiser arguments of imin_sum_decod_qc_lm (defaults MS_THR, MS_QBITS, MS_DBITS of decoders.h:46-48)."""
+        _check(self.lib, self.lib.ldpc_hip_set_ims_params(self.h, float(thr), int(qbits), int(dbits)), "ldpc_hip_set_ims_params")
 
     def set_bp_chain(self, on=True, reset_carry=False):
         """BP_DEC: chain frames through upstream's uncleared syndrome array (include/ldpc_hip.h)."""

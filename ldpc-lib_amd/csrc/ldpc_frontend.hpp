@@ -277,4 +277,35 @@ __global__ void __launch_bounds__(256) count_errors_kernel(const CountArgs a) {
     }
 }
 
+// ---- integer min-sum quantiser scale ----------------------------------------------------------------------
+// imin_sum_decod_qc_lm normalises a frame by its energy, en = sum y[i]^2 accumulated in index order (decoders.cpp:5472-5480),
+// so the rounding of that sequential sum is part of the result.  One LANE per frame walks its frame in order; the
+// [64 frames][64 values] tiles go through LDS so that the global loads stay coalesced (row stride 65: conflict free).
+struct ImsCoefArgs {
+    const double *llr;   // [B][N]
+    double *coef;        // [B] sqrt(N / en)
+    long long B;
+    int N;
+};
+
+__global__ void __launch_bounds__(64) ims_coef_kernel(const ImsCoefArgs a) {
+    __shared__ double tile[64 * 65];
+    const int lane = threadIdx.x;
+    const long long f0 = (long long)blockIdx.x * 64;
+    double en = 0;
+    for (int c0 = 0; c0 < a.N; c0 += 64) {
+        const int i = c0 + lane;
+#pragma unroll 8
+        for (int f = 0; f < 64; ++f) {
+            const long long fr = f0 + f;
+            tile[f * 65 + lane] = (fr < a.B && i < a.N) ? a.llr[fr * a.N + i] : 0.0;   // + 0*0 leaves the sum untouched
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) { const double v = tile[lane * 65 + j]; en += v * v; }
+        __syncthreads();
+    }
+    if (f0 + lane < a.B) a.coef[f0 + lane] = sqrt((double)a.N / en);                    // :5481
+}
+
 }  // namespace ldpc

@@ -60,6 +60,8 @@ constexpr int kRWM = 16;   // max circulants per block row (edge-sign bits per r
 LDPC_AOT_KERNEL(ms_spec_appendix_c_m64_kernel, ms_m64_body, CodeAppendixCM64, 64, 2)
 LDPC_AOT_KERNEL(ms_spec_appendix_c_m126_kernel, ms_body, CodeAppendixCM126, 128, 2)
 LDPC_AOT_KERNEL(ms_spec_appendix_c_m512_kernel, ms_body, CodeAppendixCM512, 512, 2)
+LDPC_AOT_KERNEL(ims_spec_appendix_c_m64_kernel, ims_body, CodeAppendixCM64, 64, 2)
+LDPC_AOT_KERNEL(ims_spec_appendix_c_m126_kernel, ims_body, CodeAppendixCM126, 128, 2)
 LDPC_AOT_KERNEL(lms_spec_appendix_c_m64_kernel, lms_body, CodeAppendixCM64, 64, 2)
 LDPC_AOT_KERNEL(lms_spec_appendix_c_m512_kernel, lms_body, CodeAppendixCM512, 512, 2)
 // two frames per CU (<= 128 VGPRs, a few spills) beats one frame with 243 VGPRs: 4.18 vs 3.70 M frames/s at 2 dB
@@ -139,6 +141,8 @@ const AotInstance kAot[] = {
     {LDPC_HIP_MS_DEC, (const void *)ms_spec_appendix_c_m64_kernel, 64, "ms_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_MS_DEC, (const void *)ms_spec_appendix_c_m126_kernel, 128, "ms_spec_appendix_c_m126_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM126>},
     {LDPC_HIP_MS_DEC, (const void *)ms_spec_appendix_c_m512_kernel, 512, "ms_spec_appendix_c_m512_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM512>},
+    {LDPC_HIP_IMS_DEC, (const void *)ims_spec_appendix_c_m64_kernel, 64, "ims_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
+    {LDPC_HIP_IMS_DEC, (const void *)ims_spec_appendix_c_m126_kernel, 128, "ims_spec_appendix_c_m126_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM126>},
     {LDPC_HIP_LMS_DEC, (const void *)lms_spec_appendix_c_m64_kernel, 64, "lms_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_LMS_DEC, (const void *)lms_spec_appendix_c_m512_kernel, 512, "lms_spec_appendix_c_m512_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM512>},
     {LDPC_HIP_SP_DEC, (const void *)sp_spec_appendix_c_m64_kernel, 512, "sp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
@@ -157,6 +161,7 @@ struct ldpc_hip_ctx {
     int F = 1;         // frames per workgroup (M <= 64: floor(64/M))
     int threads = 64;  // workgroup size
     bool multiwave = false;
+    bool have_generic = false;   // a table-driven kernel serves this decoder / code shape
     size_t lds_bytes = 0;
     double ims_thr = 1.4;  // MS_THR, MS_QBITS, MS_DBITS (decoders.h:46-48), see ldpc_hip_set_ims_params
     int ims_qbits = 6, ims_dbits = 8;
@@ -171,12 +176,17 @@ struct ldpc_hip_ctx {
     int spec_threads = 64;
     size_t spec_lds = 0;
     std::string kernel_name;  // what this context launches (ldpc_hip_kernel_name)
+    std::string generic_name; // the table-driven kernel of this decoder, if one serves this code shape
+    const char *last_launch = "";  // ldpc_hip_last_launch
     // BP_DEC: upstream's input check sees the syndrome the previous frame left in DEC_STATE::syndr (decoders.cpp:1742-1762)
     bool bp_chain = true;                 // ldpc_hip_set_bp_chain
     std::vector<uint32_t> bp_carry;       // [R/32] syndrome left behind by the last frame decoded on this context
     uint32_t *d_bp_stale = nullptr, *d_bp_synd = nullptr;
     int32_t *d_bp_idx = nullptr;
     long long bp_frames = 0;
+    // IMS_DEC: per-frame quantiser scale for the code-specialised kernel (ims_coef_kernel)
+    double *d_ims_coef = nullptr;
+    long long ims_coef_frames = 0;
     // device tables of the generic kernels
     int32_t *d_row_start = nullptr, *d_col_start = nullptr;
     uint32_t *d_edges = nullptr, *d_col_edges = nullptr, *d_col_slot = nullptr, *d_edge_row = nullptr;
@@ -245,6 +255,11 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
     case LDPC_HIP_LMS_DEC:
         if (M >= 48 && M <= 512 && soft_lds <= 160 * 1024) { p.body = "lms_body"; p.threads = 64 * W; p.lds = soft_lds; }
         break;
+    case LDPC_HIP_IMS_DEC: {   // int8 messages: MS_DBITS <= 8 and ialpha <= 16, checked per launch (the generic kernel takes the rest)
+        const size_t lds = (((size_t)2 * N + 15) & ~(size_t)15) + (size_t)t.rh * 2 * 2 * M * 4 + 16;
+        if (M >= 48 && M <= 512 && t.max_rw <= 8 && lds <= 160 * 1024) { p.body = "ims_body"; p.threads = 64 * W; p.lds = lds; }
+        break;
+    }
     case LDPC_HIP_SP_DEC: {
         const size_t lds = ldpc::sp_lds_bytes(t.ne, M, t.rh * M, N);
         if (M % 64 == 0 && lds <= 160 * 1024) { p.body = "sp_body"; p.threads = 512; p.lds = lds; }
@@ -341,6 +356,9 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
         have_generic = c->N <= ldpc::kSpNVM * c->threads && c->lds_bytes <= 160 * 1024;
     }
 
+    c->have_generic = have_generic;
+    if (have_generic) c->generic_name = c->kernel_name;
+
     // ---- code-specialised instance: ahead of time for the shipped example code, hiprtc for anything else
     const SpecPlan plan = plan_spec(decoder_id, t);
     std::string why_not = plan.body ? "" : "this code shape has no code-specialised kernel";
@@ -398,6 +416,7 @@ void ldpc_hip_close(ldpc_hip_ctx *c) {
     if (c->d_col_slot) (void)hipFree(c->d_col_slot);
     if (c->d_edge_row) (void)hipFree(c->d_edge_row);
     if (c->w_counters) (void)hipFree(c->w_counters);
+    if (c->d_ims_coef) (void)hipFree(c->d_ims_coef);
     if (c->d_bp_stale) (void)hipFree(c->d_bp_stale);
     if (c->d_bp_synd) (void)hipFree(c->d_bp_synd);
     if (c->d_bp_idx) (void)hipFree(c->d_bp_idx);
@@ -410,6 +429,7 @@ int ldpc_hip_r(const ldpc_hip_ctx *c) { return c ? c->R : 0; }
 int ldpc_hip_edges(const ldpc_hip_ctx *c) { return c ? c->ne : 0; }
 int ldpc_hip_hard_words(const ldpc_hip_ctx *c) { return c ? c->hard_words : 0; }
 const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *c) { return c ? c->kernel_name.c_str() : ""; }
+const char *ldpc_hip_last_launch(const ldpc_hip_ctx *c) { return c ? c->last_launch : ""; }
 
 int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int maxiter, double alpha,
                         uint32_t *d_hard, int32_t *d_iters, double *d_soft, void *stream_) {
@@ -429,9 +449,31 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
         HIP_TRY(hipEventCreate(&ev1));
         HIP_TRY(hipEventRecord(ev0, stream));
     }
-    if (c->spec_aot || c->spec_jit) {
+    bool use_spec = c->spec_aot || c->spec_jit;
+    const int ims_ialpha = (int)(alpha * (1 << 4));   // decoders.cpp:5458, MS_ALPHA_FPP = 4
+    if (use_spec && c->decoder_id == LDPC_HIP_IMS_DEC && (c->ims_dbits > 8 || ims_ialpha < 0 || ims_ialpha > 16)) {
+        if (!c->have_generic)
+            return fail(LDPC_HIP_EUNSUPPORTED, "integer min-sum with dbits=%d, alpha=%g needs the generic kernel, which does not support this code shape",
+                        c->ims_dbits, alpha);
+        use_spec = false;   // values beyond int8: table-driven int32 kernel
+    }
+    c->last_launch = use_spec ? c->kernel_name.c_str() : c->generic_name.c_str();
+    if (use_spec) {
         // code-specialised kernel: one frame per workgroup
         ldpc_spec::SpecArgs sa{};
+        if (c->decoder_id == LDPC_HIP_IMS_DEC) {
+            if (B > c->ims_coef_frames) {
+                if (c->d_ims_coef) (void)hipFree(c->d_ims_coef);
+                c->d_ims_coef = nullptr; c->ims_coef_frames = 0;
+                HIP_TRY(hipMalloc(&c->d_ims_coef, sizeof(double) * (size_t)B));
+                c->ims_coef_frames = B;
+            }
+            ldpc::ImsCoefArgs ca{d_llr, c->d_ims_coef, B, c->N};
+            hipLaunchKernelGGL(ldpc::ims_coef_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, ca);
+            HIP_TRY(hipGetLastError());
+            sa.ims_coef = c->d_ims_coef; sa.ims_thr = c->ims_thr;
+            sa.ims_max_quant = (1 << (c->ims_qbits - 1)) - 1; sa.ims_max_data = (1 << (c->ims_dbits - 1)) - 1; sa.ims_ialpha = ims_ialpha;
+        }
         sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
         auto launch = [&](long long blocks) -> int {
             void *kargs[] = {&sa};

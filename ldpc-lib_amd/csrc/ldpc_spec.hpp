@@ -38,6 +38,10 @@ struct SpecArgs {
     const u32 *stale;     // [B][R/32] syndrome the previous call left behind (upstream's DEC_STATE::syndr), or null = zeros
     u32 *synd_out;        // [B][R/32] syndrome this call leaves behind, or null
     const int *frame_idx; // [gridDim.x] frame decoded by each workgroup, or null = blockIdx.x
+    // ims_body only: imin_sum_decod_qc_lm's quantiser (decoders.cpp:5445-5500)
+    const double *ims_coef;   // [B] sqrt(N / sum y^2) per frame, from ims_coef_kernel (the sum is sequential: its rounding is part of the result)
+    double ims_thr;
+    int ims_max_quant, ims_max_data, ims_ialpha;
 };
 
 template <int I> struct IC { static constexpr int value = I; };
@@ -1168,6 +1172,233 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
         static_for<0, NH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
             if (wave == V.col_wave[u]) a.soft_out[fr * N + k * M + ch * 64 + lane] = so[q];
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Integer min-sum (upstream imin_sum_decod_qc_lm, decoders.cpp:5430-5690, decoder id 4), code-specialised, for
+// max_data <= 127 (MS_DBITS <= 8) and ialpha <= 16: every value is an int8.  One frame per workgroup of ceil(M/64) waves;
+// lane n is check row n of every block row AND variable n of every block column.
+//
+// Upstream's STATE1 adds the check-to-variable messages into soft[] one edge after the other and SATURATES after every add
+// (:5568), so the sum is order dependent and cannot be an atomic scatter.  Here the check lane publishes the messages of a
+// block row as bytes (<= 8 edges -> 2 dwords per check) and the VARIABLE lane walks its column's edges in upstream's order
+// (rows ascending) with one ds_read_i8 + add + med3 per edge; STATE2 (+ channel value, saturate) follows in registers.
+// STATE3 runs on the check lane like the fp64 kernels, with (|v2c| << 3 | slot) as the key of a min / med3 pair, so
+// "first minimum wins" (:5650) falls out of the integer order; the message it sends is then built for all 8 slots at once
+// with byte-parallel arithmetic (EMIT below).  The message a check sent IS the value upstream recomputes from the old
+// record in STATE3 (:5628-5631), so the record itself is never stored.
+// Both LDS arrays are stored twice, M elements apart, so that a rotated access is base + lane + immediate.
+//   soft2[k][2M]        int8   a-posteriori values
+//   msg2[j][2][2M]      dword  4 message bytes each (two's complement), slots 0-3 / 4-7 of block row j
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int med3i(int x, int y, int z) {   // median of three (clang has no builtin for the integer form)
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+}
+
+template <class C>
+struct ColView {   // column view of the code, compile time
+    int cw[C::NH] = {};
+    int cj[C::NH][C::RH] = {}, cs[C::NH][C::RH] = {}, cc[C::NH][C::RH] = {};   // block row, slot in that row, shift; rows ascending
+    constexpr ColView() {
+        for (int j = 0; j < C::RH; ++j)
+            for (int s = 0; s < C::RW[j]; ++s) {
+                const int k = C::COL[j][s];
+                cj[k][cw[k]] = j; cs[k][cw[k]] = s; cc[k][cw[k]] = C::SH[j][s];
+                ++cw[k];
+            }
+    }
+};
+
+template <class C>
+__device__ __forceinline__ void ims_body(const SpecArgs &a) {
+    static_assert(C::WMAX <= 8, "ims_body: at most 8 circulants per block row (message bytes in 2 dwords)");
+    constexpr ColView<C> V{};
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, W = (M + 63) / 64;
+    extern __shared__ double lds[];
+    char *const softb = reinterpret_cast<char *>(lds);                     // soft2[k][2M] int8
+    char *const msgb = softb + ((2 * N + 15) & ~15);                       // msg2[j][2][2M] dwords
+    int *const flag = reinterpret_cast<int *>(msgb + (size_t)RH * 2 * 2 * M * 4);
+    const int n = threadIdx.x;
+    const bool valid = (M % 64 == 0) || n < M;
+    const int nv = valid ? n : 0;
+    const long long fr = blockIdx.x;
+    const int md = a.ims_max_data, nmd = -a.ims_max_data;
+    // Lanes talk to each other through LDS.  Several waves: a workgroup barrier.  One wave: LDS executes a wave's accesses in
+    // program order, but the COMPILER only sees one thread and would move a load of [base + lane + c] above the store to
+    // [base + lane] it "cannot alias" -- a compiler-level fence keeps the phases apart.
+    auto phase_fence = [&]() {
+        if constexpr (W > 1) __syncthreads();
+        else asm volatile("" ::: "memory");
+    };
+    auto sat = [&](int x) { return med3i(x, nmd, md); };   // limit_val :4308
+    auto vote = [&](bool fail) -> bool {
+        if constexpr (W == 1) return __ballot(fail) != 0ull;
+        else {
+            if (threadIdx.x == 0) *flag = 0;
+            __syncthreads();
+            if (__ballot(fail) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+            __syncthreads();
+            const bool r = *flag != 0;
+            __syncthreads();
+            return r;
+        }
+    };
+
+    int iy[NH];                                                             // :5472-5500 energy-normalised quantiser
+    {
+        const double coef = a.ims_coef[fr];
+        const double *yrow = a.llr + fr * N + nv;
+        static_for<0, NH>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            double val = yrow[k * M];
+            int sign = 0;
+            if (val < 0) { val = -val; sign = 1; }
+            val *= coef;
+            if (val > a.ims_thr) val = a.ims_thr;
+            const int ival = (int)(short)floor(val * a.ims_max_quant / a.ims_thr + 0.5);
+            iy[k] = sign ? -ival : ival;
+        });
+    }
+    u32 pm[RH][2];                                                          // the messages this check sent last (bytes)
+    static_for<0, RH>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        pm[j][0] = 0u; pm[j][1] = 0u;                                       // all-zero records :5462-5470 -> zero messages
+        if (valid) {
+            static_for<0, 2>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                u32 *p = reinterpret_cast<u32 *>(msgb + ((size_t)(j * 2 + q) * 2 * M + nv) * 4);
+                p[0] = 0u; p[M] = 0u;
+            });
+        }
+    });
+    phase_fence();
+
+    int res = -a.maxiter;
+    for (int iter = 0; iter < a.maxiter; ++iter) {
+        // ---------------- STATE1 + STATE2 on the variable lane (:5540-5604)
+        // Software pipeline: the message bytes of column group g+1 are requested before group g is summed, and soft2 is
+        // written only after every column is done (the compiler cannot tell msg2 from soft2, so a store in between would
+        // pin all later loads behind it: one exposed LDS round trip per column).
+        int softv[NH];
+        {
+            constexpr int G = 4, NG = (NH + G - 1) / G;
+            int mv[2][G][RH];
+            auto request = [&](auto GI) {
+                constexpr int g = decltype(GI)::value;
+                static_for<g * G, (g * G + G < NH ? g * G + G : NH)>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    static_for<0, V.cw[k]>([&](auto X) {
+                        constexpr int x = decltype(X)::value, j = V.cj[k][x], s = V.cs[k][x], c = V.cc[k][x];
+                        constexpr int off = ((j * 2 + (s >> 2)) * 2 * M + (M - c) % M) * 4 + (s & 3);
+                        mv[g & 1][k % G][x] = (int)*reinterpret_cast<const signed char *>(msgb + off + nv * 4);
+                    });
+                });
+            };
+            request(IC<0>{});
+            static_for<0, NG>([&](auto GI) {
+                constexpr int g = decltype(GI)::value;
+                if constexpr (g + 1 < NG) request(IC<g + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<g * G, (g * G + G < NH ? g * G + G : NH)>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    int acc = 0;
+                    static_for<0, V.cw[k]>([&](auto X) { acc = sat(acc + mv[g & 1][k % G][decltype(X)::value]); });   // rows ascending, saturate per add :5568
+                    softv[k] = sat(iy[k] + acc);                                                                       // :5590-5597
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        if (valid) {
+            static_for<0, NH>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                signed char *p = reinterpret_cast<signed char *>(softb + k * 2 * M + nv);
+                p[0] = (signed char)softv[k]; p[M] = (signed char)softv[k];
+            });
+        }
+        phase_fence();
+        // ---------------- STATE3 on the check lane (:5610-5678) + the messages of the next STATE1
+        u32 failw = 0;
+        int rb[2][8];                                                         // soft values of block row j / j+1 (same pipeline)
+        auto request_row = [&](auto JI) {
+            constexpr int j = decltype(JI)::value;
+            static_for<0, C::RW[j]>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                rb[j & 1][s] = (int)*reinterpret_cast<const signed char *>(softb + C::COL[j][s] * 2 * M + C::SH[j][s] + nv);
+            });
+        };
+        request_row(IC<0>{});
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int RW = C::RW[j];
+            if constexpr (j + 1 < RH) request_row(IC<j + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            int r[RW];
+            static_for<0, RW>([&](auto S) { r[decltype(S)::value] = rb[j & 1][decltype(S)::value]; });
+            u32 k1 = (u32)md << 3, k2 = (u32)md << 3, slo = 0u, shi = 0u, par = 0u, sy = 0u;
+            static_for<0, RW>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                const int t = __builtin_amdgcn_sbfe((int)pm[j][s >> 2], 8 * (s & 3), 8);
+                const int msg = r[s] - t;                                     // :5633
+                sy ^= (u32)r[s];
+                par ^= (u32)msg;
+                // byte 3 of msg is 0x00 / 0xff = its sign: drop it into byte (s & 3) of the row's sign-byte word
+                constexpr u32 sel = (0x03020100u & ~(0xffu << (8 * (s & 3)))) | (0x07u << (8 * (s & 3)));
+                if constexpr (s < 4) slo = __builtin_amdgcn_perm((u32)msg, slo, sel);
+                else shi = __builtin_amdgcn_perm((u32)msg, shi, sel);
+                const int neg = t - r[s];
+                const u32 key = ((u32)(msg > neg ? msg : neg) << 3) | (u32)s;   // |msg|; the clamp to max_data (:5645) is in the start value
+                k2 = (u32)med3i((int)key, (int)k1, (int)k2);
+                k1 = key < k1 ? key : k1;
+            });
+            failw |= sy;
+            // EMIT: message of slot s = sign_s ^ parity ? -mag_s : mag_s, mag_s = (s == pos ? min2 : min1) * ialpha >> 4  (:5556-5566)
+            const u32 a1 = ((k1 >> 3) * (u32)a.ims_ialpha) >> 4, a2 = ((k2 >> 3) * (u32)a.ims_ialpha) >> 4;
+            const u32 A = __builtin_amdgcn_perm(a1, a1, 0u);                  // a1 in all four bytes
+            const u64 dd = (u64)(a1 ^ a2) << ((k1 & 7u) * 8u);                // turns byte `pos` into a2
+            const u32 mlo = A ^ (u32)dd, mhi = A ^ (u32)(dd >> 32);
+            const u32 pw = (u32)((int)par >> 31);
+            const u32 nlo = slo ^ pw, nhi = shi ^ pw;                          // 0xff where the message is negative
+            constexpr u32 K80 = 0x80808080u;
+            const u32 ql = (K80 - mlo) ^ K80, qh = (K80 - mhi) ^ K80;          // -mag per byte (mag <= 127: no borrow between bytes)
+            pm[j][0] = (nlo & ql) | (~nlo & mlo);
+            pm[j][1] = (nhi & qh) | (~nhi & mhi);
+        });
+        if (valid) {                                                          // published after ALL rows have read soft2 (see above)
+            static_for<0, RH>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                u32 *p0 = reinterpret_cast<u32 *>(msgb + ((size_t)(j * 2 + 0) * 2 * M + nv) * 4);
+                p0[0] = pm[j][0]; p0[M] = pm[j][0];
+                if constexpr (C::RW[j] > 4) {
+                    u32 *p1 = reinterpret_cast<u32 *>(msgb + ((size_t)(j * 2 + 1) * 2 * M + nv) * 4);
+                    p1[0] = pm[j][1]; p1[M] = pm[j][1];
+                }
+            });
+        }
+        if constexpr (W == 1) phase_fence();                                  // (the vote's barriers do it for several waves)
+        if (!vote(valid && (failw >> 31) != 0)) { res = iter + 1; break; }    // :5684-5689
+    }
+
+    if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
+    phase_fence();
+    if (a.hard) {
+        constexpr int HW = (N + 31) / 32;
+        for (int w = threadIdx.x; w < HW; w += W * 64) {
+            u32 bits = 0;
+            for (int b = 0; b < 32; ++b) {
+                const int v = 32 * w + b;
+                if (v < N) bits |= ((u32)(int)*reinterpret_cast<const signed char *>(softb + (v / M) * 2 * M + v % M) >> 31) << b;
+            }
+            a.hard[fr * HW + w] = bits;
+        }
+    }
+    if (a.soft_out && valid) {
+        static_for<0, NH>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            a.soft_out[fr * N + k * M + n] = (double)*reinterpret_cast<const signed char *>(softb + k * 2 * M + n);
         });
     }
 }

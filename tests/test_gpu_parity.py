@@ -84,7 +84,10 @@ def test_golden_vectors_host_api(L, name):
     (SP_DEC, 33, (2.0,), 40, 25),
     (IMS_DEC, 64, (1.0, 2.0, 3.0), 150, 50),   # int16 min-sum: exact by construction after the quantiser
     (IMS_DEC, 20, (3.0,), 100, 50),
-    (IMS_DEC, 126, (2.0,), 24, 50),
+    (IMS_DEC, 126, (2.0,), 24, 50),            # ahead-of-time int8 instance, 2 waves per frame, 2 idle lanes
+    (IMS_DEC, 100, (1.5, 2.5), 30, 50),        # hiprtc int8 instance, 28 idle lanes
+    (IMS_DEC, 256, (1.8,), 12, 50),            # hiprtc int8 instance, 4 waves per frame
+    (IMS_DEC, 512, (1.8,), 6, 50),             # LDS would not hold the doubled arrays: table-driven kernel
     (TASP_DEC, 64, (1.0, 1.7, 2.5), 120, 15),   # TDMP sum-product, ahead-of-time instance
     (TASP_DEC, 126, (1.7,), 24, 15),            # the shipped scenario's lifting, 2 waves per frame
     (TASP_DEC, 40, (2.5,), 60, 30),             # hiprtc instance, 24 idle lanes
@@ -415,6 +418,36 @@ def test_decoders_h_call_surface(L, tmp_path, name):
             assert np.array_equal(after, llr)          # MS/LMS leave y intact (SURVEY 8b ownership)
         else:
             assert not np.array_equal(after, llr)      # SP clobbers its input like upstream (decoders.cpp:1950)
+
+
+@pytest.mark.parametrize("thr,qbits,dbits,alpha,expect", [
+    (1.4, 6, 8, 0.8, "ims_spec"),       # upstream defaults: int8 code-specialised kernel
+    (1.4, 6, 8, 1.0, "ims_spec"),       # ialpha = 16, still int8
+    (2.0, 7, 8, 0.75, "ims_spec"),
+    (1.4, 6, 10, 0.8, "ims_flood"),     # 10-bit data: beyond int8 -> table-driven int32 kernel, same results as the oracle
+    (1.4, 6, 8, 1.25, "ims_flood"),     # ialpha = 20 > 16
+])
+def test_integer_min_sum_parameters_pick_the_right_kernel(L, torch, thr, qbits, dbits, alpha, expect):
+    import ctypes as C
+    from ldpc_testlib import _as_double_p, oracle_lib
+    H = relift(load_base_matrix(), 64)
+    llr = np.concatenate([awgn_llr(H, 64, s, 40 + i, 30) for i, s in enumerate((1.2, 2.2, 3.0))])
+    o = Oracle(H, 64)
+    lib = oracle_lib()
+    lib.orc_imin_sum.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
+    want_it = np.zeros(len(llr), dtype=np.int32)
+    want_soft = np.zeros_like(llr)
+    for f in range(len(llr)):
+        y = llr[f].copy()
+        want_it[f] = lib.orc_imin_sum(o.h, _as_double_p(y), _as_double_p(want_soft[f]), 50, 1, alpha, thr, qbits, dbits)
+    with L.LdpcHip(IMS_DEC, H, 64) as dec:
+        dec.set_ims_params(thr, qbits, dbits)
+        hard, iters, soft = dec.decode(torch.from_numpy(llr).cuda(), 50, alpha=alpha, want_soft=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(iters.cpu().numpy(), want_it)
+        assert np.array_equal(soft.cpu().numpy(), want_soft)
+        assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits((want_soft < 0).astype(np.float64)))
+        assert expect in dec.last_launch(), dec.last_launch()
 
 
 def test_bp_frames_chain_through_the_uncleared_syndrome(L):
