@@ -520,3 +520,37 @@ def test_c_example_runs(L, tmp_path):
     out = subprocess.check_output([exe, os.path.join(GOLDEN_DIR, "h16x32_m126.txt"), "64", "3", "50", "2.0", "2.0", "1", "100000"]).decode()
     row = [ln for ln in out.splitlines() if not ln.startswith("#")][0].split()
     assert abs(float(row[1]) - 0.0425) < 0.004, out
+
+
+def test_ldpc_sim_driver_reproduces_the_sequential_harness(L, tmp_path):
+    """`ldpc_sim simulation`: jsonx scenario in, result records out; every (code, SNR) point must equal the
+    sequential CPU restatement of upstream's bp_simulation on the same generator seed -- and the three points the survey
+    measured with the compiled upstream binary (112, 13 and 124 errored frames in 2001)."""
+    import ctypes as C
+    import subprocess
+    from ldpc_testlib import SimResult, c_int_p, oracle_lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _compat_lib(L)
+    exe = os.path.join(root, "ldpc-lib_amd", "ldpc_sim")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "ldpc-lib_amd", "csrc", "compat")])
+    out = str(tmp_path / "result.jsonx")
+    subprocess.check_call([exe, "simulation", os.path.join(root, "examples", "simulation_appendix_c.jsonx"), out])
+    def get(path):
+        return subprocess.check_output([exe, "jsonx-get", out, path], text=True).strip()
+    def numbers(path):
+        return [float(x) for x in get(path).replace("array {", "").replace("}", "").split()]
+    points = [(0, MS_DEC, 1, 20, [4.0], 112), (1, SP_DEC, 64, 50, [2.0], 13), (2, LMS_DEC, 512, 50, [1.6], 124), (3, MS_DEC, 64, 50, [2.0, 2.5], None)]
+    for idx, dec_id, M, maxit, snrs, survey_nde in points:
+        assert int(get(f"results/{idx}/_decoder_type")) == dec_id and int(get(f"results/{idx}/_lifting")) == M
+        H = np.ascontiguousarray(relift(load_base_matrix(), M), dtype=np.int32)
+        cells = [int(x) for x in get(f"results/{idx}/code").replace("matrix (16 32) {", "").replace("}", "").split()]
+        assert np.array_equal(np.array(cells).reshape(16, 32), H)       # shifts reduced modulo the lifting (main_simulation.cpp:400-414)
+        fer, ber = numbers(f"results/{idx}/simulation_logs/0/FER"), numbers(f"results/{idx}/simulation_logs/0/BER")
+        for s, snr in enumerate(snrs):
+            res = SimResult()
+            assert oracle_lib().orc_bp_simulation(16, 32, H.ctypes.data_as(c_int_p), M, maxit, 1000000, 2000, snr, 1.0, dec_id, 0, 0, 1,
+                                                  C.byref(res), None) == 0
+            assert res.experiment == 2001
+            assert fer[s] == res.fer and ber[s] == res.ber
+            if survey_nde is not None:
+                assert res.nde == survey_nde

@@ -158,3 +158,81 @@ def test_c_example_builds_against_the_header(tmp_path):
                            "-o", str(exe), "-L", os.path.join(ROOT, "ldpc-lib_amd"), "-lldpc_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "ldpc-lib_amd")])
     assert exe.exists()
+
+
+# ---- jsonx reader / writer and the `ldpc_sim` driver -------------------------------------------------------
+def _ldpc_sim():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "ldpc-lib_amd", "csrc", "compat")])
+    exe = os.path.join(root, "ldpc-lib_amd", "ldpc_sim")
+    assert os.path.exists(exe)
+    return exe
+
+
+def test_jsonx_reader_follows_upstreams_grammar(tmp_path):
+    """Every construct upstream's settings.cpp:178-345 reads: records, arrays, matrices, sparse matrices, strings, numbers kept
+    as text, '/'-comments, '@' file references (relative to the including file), `array @file`, first-key-wins, and select()
+    falling back to `defaults` records."""
+    import subprocess
+    exe = _ldpc_sim()
+    (tmp_path / "sub").mkdir()
+    (tmp_path / "sub" / "consts.jsonx").write_text('{ alpha = 0.8   / a single slash starts a comment\n beta = 4e-1 nested = { deep = "yes" } }')
+    (tmp_path / "sub" / "codes.jsonx").write_text('{ id = 0 m = matrix (2 3) { 0 -1 7  5 -1 -1 } }\n// second value of the sequence\n{ id = 1 }')
+    (tmp_path / "main.jsonx").write_text("""// scenario
+{
+    defaults = @"sub/consts.jsonx"
+    snrs = array { 1.7 }
+    snrs = array { 2.7 }          // ignored: the first value of a key wins (std::map::insert)
+    name = "two words"
+    results = array @"sub/codes.jsonx"
+    sp = sparse matrix (2 2) { 0 1 5   1 0 -3 }
+    settings = { defaults = { inner = 3 } x = 1e-1 list = array { array { 1 2 } array { } } }
+}""")
+    def get(path):
+        return subprocess.check_output([exe, "jsonx-get", str(tmp_path / "main.jsonx"), path], text=True).strip()
+    assert get("snrs") == "array { 1.7 }"
+    assert get("name") == "two words"
+    assert get("alpha") == "0.8" and get("beta") == "4e-1" and get("nested/deep") == "yes"     # through `defaults`, read from a file
+    assert get("settings/inner") == "3" and get("settings/x") == "1e-1"
+    assert get("results/0/m").split() == "matrix (2 3) { 0 -1 7 5 -1 -1 }".split()
+    assert get("results/1/id") == "1"
+    assert get("sp").split()[:4] == ["matrix", "(2", "2)", "{"]
+    assert get("settings/list") .split() == "array { array { 1 2 } array { } }".split()
+    assert subprocess.run([exe, "jsonx-get", str(tmp_path / "main.jsonx"), "nope"], capture_output=True).returncode == 1
+    # canonical form is a fixed point, and it is readable again
+    subprocess.check_call([exe, "jsonx", str(tmp_path / "main.jsonx"), str(tmp_path / "a.jsonx")])
+    subprocess.check_call([exe, "jsonx", str(tmp_path / "a.jsonx"), str(tmp_path / "b.jsonx")])
+    assert (tmp_path / "a.jsonx").read_text() == (tmp_path / "b.jsonx").read_text()
+    (tmp_path / "bad.jsonx").write_text("{ a = array { 1 2 ")
+    assert subprocess.run([exe, "jsonx", str(tmp_path / "bad.jsonx"), str(tmp_path / "c.jsonx")], capture_output=True).returncode == 1
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/files"), reason="upstream tree not mounted")
+def test_jsonx_reader_takes_every_file_upstream_ships(tmp_path):
+    import glob
+    import subprocess
+    exe = _ldpc_sim()
+    files = sorted(glob.glob("/root/reference/files/*.jsonx"))
+    assert len(files) >= 10
+    for f in files:
+        subprocess.check_call([exe, "jsonx", f, str(tmp_path / "a.jsonx")])
+        subprocess.check_call([exe, "jsonx", str(tmp_path / "a.jsonx"), str(tmp_path / "b.jsonx")])
+        assert (tmp_path / "a.jsonx").read_text() == (tmp_path / "b.jsonx").read_text(), f
+    def get(f, path):
+        return subprocess.check_output([exe, "jsonx-get", "/root/reference/files/" + f, path], text=True).strip()
+    assert get("input32_16.jsonx", "decoder_type") == "7" and get("input32_16.jsonx", "permutation_block") == "128"
+    assert get("resultq.jsonx", "results/0/_lifting") == "8" and get("resultq.jsonx", "settings/error_minimization/name") == "FER"
+
+
+def test_example_scenario_is_well_formed():
+    import subprocess
+    exe = _ldpc_sim()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ex = os.path.join(root, "examples", "simulation_appendix_c.jsonx")
+    def get(path):
+        return subprocess.check_output([exe, "jsonx-get", ex, path], text=True).strip()
+    assert get("settings/num_codewords") == "2000" and get("results/2/_lifting") == "512" and get("results/3/_SNRs") == "array { 2.0 2.5 }"
+    from ldpc_testlib import load_base_matrix
+    cells = [int(x) for x in get("results/0/code").replace("matrix (16 32) {", "").replace("}", "").split()]
+    assert np.array_equal(np.array(cells).reshape(16, 32), load_base_matrix())
