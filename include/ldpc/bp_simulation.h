@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "ldpc_hip.h"
+#include "ldpc/interleaver.h"
 
 namespace ldpc {
 
@@ -69,9 +70,9 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
                                           int n_frame_errors, int n_experiments, double snr,
                                           double reference_frame_error, int decoder_type, int modulation_type,
                                           int permutation_type, int punctured_blocks, int show_process,
-                                          SimCounters *counters_out = nullptr, int device = 0, long long max_batch = 4096) {
+                                          SimCounters *counters_out = nullptr, int device = 0, long long max_batch = 4096,
+                                          int permutation_block = 128, int permutation_inter = 1) {
     if (q_mod != 2) Env::fail("bp_simulation: only binary codes (q_mod == 2) are built in ldpc-lib_amd");
-    if (permutation_type != 0) Env::fail("bp_simulation: only permutation_type 0 (identity) is built in ldpc-lib_amd");
     if (modulation_type != MODULATION_SKIP_ && modulation_type != MODULATION_QAM4_)
         Env::fail("bp_simulation: exact-replay mode supports MODULATION_SKIP and MODULATION_QAM4 (upstream's QAM16+ wiring "
                   "is broken, SURVEY Appendix B Q5/Q6; use the device-side chain ldpc_hip_awgn_qam16_llr_dev)");
@@ -96,6 +97,17 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
     const double sigmaQAM = std::sqrt(std::pow(10., -snr / 10.) / (2 * bitrate * halfmlog * 2) * norm_factor);  // :449
     const double sg = modulation_type == MODULATION_SKIP_ ? sigma : sigmaQAM;
 
+    // :413-427 interleaver between demapper and decoder (identity for permutation_type 0); same maps as upstream's
+    Interleaver il;
+    {
+        std::vector<int> hflat((size_t)b * c);
+        for (int i = 0; i < b; ++i) for (int j = 0; j < c; ++j) hflat[(size_t)i * c + j] = H(i, j);
+        std::string err;
+        if (!build_interleaver(b, c, M, halfmlog, permutation_type, permutation_block, permutation_inter, hflat.data(), il, err))
+            Env::fail(err.c_str());
+    }
+    std::vector<double> chan((size_t)n);
+
     Env::burn_codeword_draws(H, M);  // :512
 
     long long nse = 0, nue = 0, nde = 0, experiment = 0, sum_abs_iters = 0;
@@ -112,8 +124,9 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
             double *y = llr.data() + (size_t)f * n;
             for (int i = 0; i < n; ++i) {                                                       // :601-611
                 const double noise = Env::gaussian();
-                y[i] = -2.0 * (sg * noise + 2.0 * 0.0 - 1.0) / (sg * sg);                         // codeword == 0 (:568)
+                chan[(size_t)i] = -2.0 * (sg * noise + 2.0 * 0.0 - 1.0) / (sg * sg);              // codeword == 0 (:568)
             }
+            for (int i = 0; i < n; ++i) y[i] = chan[(size_t)il.inverse[(size_t)i]];              // :684 inverse permutation
             const double init_val = out_type == 1 ? 0 : 0.5;                                     // :700 (sic)
             const int plen = M * punctured_blocks, pstart = n - plen;
             for (int i = pstart; i < pstart + plen; ++i) y[i] = init_val;                        // :702-709

@@ -119,11 +119,26 @@ int ldpc_hip_awgn_llr_dev(ldpc_hip_ctx *ctx, double snr_db, int modulation_type,
  * x + sigmaQAM*g per frame, per-rail soft demap with cut-off T, negated.  N must be a multiple of 4. */
 int ldpc_hip_awgn_qam16_llr_dev(ldpc_hip_ctx *ctx, double snr_db, double T, uint64_t seed, long long first_frame,
                                 long long B, double *d_llr, void *stream);
+/* The same chain for modulation_type 2 (QAM16), 3 (QAM64), 4 (QAM256) (enum MODULATION_TYPE, modulation.h:4-11;
+ * QAM_demodulator.cpp:203-561; sigmaQAM bp_simulation.cpp:447-449).  When N is not a multiple of log2 Q the last symbol is
+ * padded with zero bits like bp_simulation.cpp:575 and only its first bits are written.  Same noise keys as the 16-QAM entry. */
+int ldpc_hip_awgn_qam_llr_dev(ldpc_hip_ctx *ctx, int modulation_type, double snr_db, double T, uint64_t seed, long long first_frame,
+                              long long B, double *d_llr, void *stream);
 
-/* Function-level soft demapper: QAM_demodulator.cpp:99-566 Demodulate() for Q in {4,16}, out_type 0/1.
+/* Function-level soft demapper: QAM_demodulator.cpp:99-566 Demodulate() for Q in {4,16,64,256}, out_type 0/1 (Q = 4: out_type 0 only).
  * d_x [ns][2] (I,Q interleaved) -> d_out [ns][log2 Q]. */
 int ldpc_hip_qam_demod_dev(int Q, double T, double sigma, const double *d_x, long long ns, double *d_out,
                            int out_type, int device, void *stream);
+
+/* Bit interleavers of the simulation chain (Permutations_Open / Permutation_Init / Permutation,
+ * direct_inverse_perm.cpp:139-900; permutation_type of bp_simulation.h:21-23): mode 0 identity, 1 random, 2 deterministic,
+ * 3 block random (block_size), 4 interleaved random (step_size); halfmlog = 1 (BPSK / QAM4), 2, 3, 4 (QAM16 / 64 / 256).
+ * HOST function (no GPU needed): fills the two gather maps, out[i] = in[map[i]], direct[N] (encoder -> mapper side) and
+ * inverse[N] (demapper -> decoder side), N = c*M, identical to upstream's for the same arguments (same LCG, same order). */
+int ldpc_hip_interleaver_build(int b, int c, int M, int halfmlog, int mode, int block_size, int step_size, const int16_t *hd,
+                               int32_t *direct, int32_t *inverse);
+/* Applies a map to B frames resident on the device: d_out[f][i] = d_in[f][d_map[i]] (d_in != d_out). */
+int ldpc_hip_permute_dev(const double *d_in, double *d_out, long long B, int N, const int32_t *d_map, int device, void *stream);
 
 /* Error accounting, replaces bp_simulation.cpp:731-759,805-810 for the all-zero codeword.
  *   d_frame_info [B] int32 out (or NULL): number of wrong information bits (index >= R) of the frame, with bit 30

@@ -81,11 +81,14 @@ def load_library():
     lib.ldpc_hip_decode_host.argtypes = [vp, vp, i64, i32, i32, f64, vp, vp, i32]
     lib.ldpc_hip_awgn_llr_dev.argtypes = [vp, f64, i32, i32, u64, i64, i64, vp, vp]
     lib.ldpc_hip_awgn_qam16_llr_dev.argtypes = [vp, f64, f64, u64, i64, i64, vp, vp]
+    lib.ldpc_hip_awgn_qam_llr_dev.argtypes = [vp, i32, f64, f64, u64, i64, i64, vp, vp]
     lib.ldpc_hip_qam_demod_dev.argtypes = [i32, f64, f64, vp, i64, vp, i32, i32, vp]
     lib.ldpc_hip_count_errors_dev.argtypes = [vp, vp, vp, i64, vp, vp, vp]
     lib.ldpc_hip_simulate.argtypes = [vp, f64, i32, i32, i32, f64, u64, i64, i64, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.ldpc_hip_set_bp_chain.argtypes = [vp, i32, i32]
     lib.ldpc_hip_set_ims_params.argtypes = [vp, f64, i32, i32]
+    lib.ldpc_hip_interleaver_build.argtypes = [i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.ldpc_hip_permute_dev.argtypes = [vp, vp, i64, i32, vp, i32, vp]
     lib.ldpc_hip_profile_enable.argtypes = [vp, i32]
     lib.ldpc_hip_profile_read.argtypes = [vp, C.POINTER(f64), C.POINTER(i64), i32]
     if lib.ldpc_hip_abi_version() != 1:
@@ -176,12 +179,12 @@ class LdpcHip:
         return hard, iters, soft
 
     def awgn_llr(self, snr_db, seed, first_frame, B, modulation=0, punctured_blocks=0, out=None, stream=None, T=26.0):
-        """Device-side channel: modulation 0 BPSK, 1 QAM4 (upstream formulas), 2 16-QAM chain (as intended upstream)."""
+        """Device-side channel: modulation 0 BPSK, 1 QAM4 (upstream formulas), 2 / 3 / 4 the 16- / 64- / 256-QAM chain (as intended upstream)."""
         import torch
         llr = out if out is not None else torch.empty((B, self.N), dtype=torch.float64, device=self._dev())
-        if modulation == 2:
-            rc = self.lib.ldpc_hip_awgn_qam16_llr_dev(self.h, float(snr_db), float(T), int(seed), int(first_frame), int(B),
-                                                      llr.data_ptr(), _stream_ptr(stream))
+        if modulation >= 2:
+            rc = self.lib.ldpc_hip_awgn_qam_llr_dev(self.h, int(modulation), float(snr_db), float(T), int(seed), int(first_frame), int(B),
+                                                    llr.data_ptr(), _stream_ptr(stream))
         else:
             rc = self.lib.ldpc_hip_awgn_llr_dev(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(seed),
                                                 int(first_frame), int(B), llr.data_ptr(), _stream_ptr(stream))
@@ -237,6 +240,30 @@ class LdpcHip:
         ms, n = C.c_double(), C.c_longlong()
         _check(self.lib, self.lib.ldpc_hip_profile_read(self.h, C.byref(ms), C.byref(n), 1 if reset else 0), "ldpc_hip_profile_read")
         return ms.value, n.value
+
+
+def build_interleaver(H, M, mode, halfmlog=1, block_size=128, step_size=1):
+    """Gather maps (direct, inverse) of upstream's interleaver `mode` (permutation_type) for base matrix H: out[i] = in[map[i]].
+    Host-side, needs no GPU."""
+    lib = load_library()
+    H = np.ascontiguousarray(H, dtype=np.int16)
+    b, c = H.shape
+    direct = np.empty(c * M, dtype=np.int32)
+    inverse = np.empty(c * M, dtype=np.int32)
+    rc = lib.ldpc_hip_interleaver_build(b, c, int(M), int(halfmlog), int(mode), int(block_size), int(step_size), H.ctypes.data,
+                                        direct.ctypes.data, inverse.ctypes.data)
+    _check(lib, rc, "ldpc_hip_interleaver_build")
+    return direct, inverse
+
+
+def permute(x, index_map, device=0, stream=None):
+    """y[f, i] = x[f, index_map[i]] on the GPU (x float64 CUDA [B, N], index_map int32 CUDA [N])."""
+    import torch
+    lib = load_library()
+    y = torch.empty_like(x)
+    rc = lib.ldpc_hip_permute_dev(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], index_map.data_ptr(), device, _stream_ptr(stream))
+    _check(lib, rc, "ldpc_hip_permute_dev")
+    return y
 
 
 def qam_demod(x, Q, T, sigma, out_type=0, device=0, stream=None):

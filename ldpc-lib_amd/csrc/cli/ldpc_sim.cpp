@@ -161,8 +161,8 @@ int main(int argc, char **argv) {
                     ldpc::Matrix coef;
                     const std::pair<double, double> p = ldpc::bp_simulation_t<ldpc::Matrix, ldpc::OwnRngEnv>(
                         2, H, lifting, iterations, num_frame_errors, (int)num_experiments, snrs[s], error_rate_threshold, decoder_type,
-                        modulation_type, permutation_type, punctured_blocks, 0, nullptr, device);
-                    (void)coef; (void)permutation_block; (void)permutation_inter;
+                        modulation_type, permutation_type, punctured_blocks, 0, nullptr, device, 4096, permutation_block, permutation_inter);
+                    (void)coef;
                     res = {p.first, p.second};
                 }
                 if (res.ber < 0 || res.fer < 0) res = {1.0, 1.0};                                                            // :527-531

@@ -37,11 +37,12 @@ std::pair<double, double> bp_simulation(int q_mod, matrix<int> const &code_gener
                                         int n_experiments, double snr, double reference_frame_error, int decoder_type,
                                         int modulation_type, int permutation_type, int permutation_block,
                                         int permutation_inter, int punctured_blocks, int show_process) {
-    (void)coef_matrix; (void)ncols2convert; (void)permutation_block; (void)permutation_inter;  // q_mod > 2 / interleaver only
+    (void)coef_matrix; (void)ncols2convert;  // q_mod > 2 only
     return ldpc::bp_simulation_t<matrix<int>, UpstreamRngEnv>(q_mod, code_generating_matrix, tailbite_length, max_iterations,
                                                               n_frame_errors, n_experiments, snr, reference_frame_error,
                                                               decoder_type, modulation_type, permutation_type,
-                                                              punctured_blocks, show_process);
+                                                              punctured_blocks, show_process, nullptr, 0, 4096, permutation_block,
+                                                              permutation_inter);
 }
 
 // the definition above must be THE function upstream's header declares (not an overload)

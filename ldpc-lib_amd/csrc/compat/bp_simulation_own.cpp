@@ -37,31 +37,39 @@ double next_random_gaussian() {  // :174-178: a fresh distribution per call (the
 
 std::pair<double, double> bp_simulation(int q_mod, Matrix const &H, Matrix &, int, int tailbite_length, int max_iterations,
                                         int n_frame_errors, int n_experiments, double snr, double reference_frame_error,
-                                        int decoder_type, int modulation_type, int permutation_type, int, int,
-                                        int punctured_blocks, int show_process) {
+                                        int decoder_type, int modulation_type, int permutation_type, int permutation_block,
+                                        int permutation_inter, int punctured_blocks, int show_process) {
     return bp_simulation_t<Matrix, OwnRngEnv>(q_mod, H, tailbite_length, max_iterations, n_frame_errors, n_experiments, snr,
                                               reference_frame_error, decoder_type, modulation_type, permutation_type,
-                                              punctured_blocks, show_process);
+                                              punctured_blocks, show_process, nullptr, 0, 4096, permutation_block, permutation_inter);
 }
 
 }  // namespace ldpc
 
 // C entry point: H row-major rh x nh; seeds the generator like `initial_random_seed = seed; reset_random();`.
 // out[0..6] = BER, FER, nse, nde, nue, experiment, sum|iters|; *rng_next = next raw mt19937 output (state fingerprint).
-extern "C" int ldpc_bp_simulation_exact(int rh, int nh, const int *H, int M, int max_iterations, int n_frame_errors,
-                                        int n_experiments, double snr, double reference_frame_error, int decoder_type,
-                                        int modulation_type, int punctured_blocks, unsigned seed, int device, double out[7],
-                                        unsigned *rng_next) {
+extern "C" int ldpc_bp_simulation_exact_perm(int rh, int nh, const int *H, int M, int max_iterations, int n_frame_errors,
+                                             int n_experiments, double snr, double reference_frame_error, int decoder_type,
+                                             int modulation_type, int permutation_type, int permutation_block, int permutation_inter,
+                                             int punctured_blocks, unsigned seed, int device, double out[7], unsigned *rng_next) {
     ldpc::Matrix mat(rh, nh);
     for (int i = 0; i < rh * nh; ++i) mat.v[(size_t)i] = H[i];
     ldpc::initial_random_seed = (int)seed;
     ldpc::reset_random();
     ldpc::SimCounters cnt;
     const std::pair<double, double> res = ldpc::bp_simulation_t<ldpc::Matrix, ldpc::OwnRngEnv>(
-        2, mat, M, max_iterations, n_frame_errors, n_experiments, snr, reference_frame_error, decoder_type, modulation_type, 0,
-        punctured_blocks, 0, &cnt, device);
+        2, mat, M, max_iterations, n_frame_errors, n_experiments, snr, reference_frame_error, decoder_type, modulation_type,
+        permutation_type, punctured_blocks, 0, &cnt, device, 4096, permutation_block, permutation_inter);
     out[0] = res.first; out[1] = res.second; out[2] = (double)cnt.nse; out[3] = (double)cnt.nde; out[4] = (double)cnt.nue;
     out[5] = (double)cnt.experiment; out[6] = (double)cnt.sum_abs_iters;
     if (rng_next) *rng_next = (unsigned)ldpc::random_generator()();
     return 0;
+}
+
+extern "C" int ldpc_bp_simulation_exact(int rh, int nh, const int *H, int M, int max_iterations, int n_frame_errors,
+                                        int n_experiments, double snr, double reference_frame_error, int decoder_type,
+                                        int modulation_type, int punctured_blocks, unsigned seed, int device, double out[7],
+                                        unsigned *rng_next) {
+    return ldpc_bp_simulation_exact_perm(rh, nh, H, M, max_iterations, n_frame_errors, n_experiments, snr, reference_frame_error,
+                                         decoder_type, modulation_type, 0, 128, 1, punctured_blocks, seed, device, out, rng_next);
 }

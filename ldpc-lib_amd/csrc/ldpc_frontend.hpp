@@ -1,7 +1,7 @@
 // ldpc_frontend.hpp -- channel front end and error accounting kernels around the decoders (gfx950).
 //
 //   awgn_llr_kernel        bp_simulation.cpp:444-449,600-612,697-710  (BPSK / QAM4 LLRs of the all-zero codeword)
-//   awgn_qam16_llr_kernel  QAM_modulator.cpp:142 + bp_simulation.cpp:621-628 (as intended) + QAM_demodulator.cpp:203-275
+//   awgn_qam_llr_kernel<H> QAM_modulator.cpp:142 + bp_simulation.cpp:621-628 (as intended) + QAM_demodulator.cpp:203-561, 16/64/256-QAM
 //   qam_demod_kernel       QAM_demodulator.cpp:99-566 Demodulate(), Q in {4,16,64,256}
 //   count_errors_kernel    bp_simulation.cpp:731-759,805-810
 //
@@ -194,33 +194,43 @@ __global__ void __launch_bounds__(256) qam_demod_kernel(const DemodArgs a) {
     }
 }
 
-struct Qam16Args {
-    double *llr;  // [B][N], N % 4 == 0
+struct QamArgs {
+    double *llr;  // [B][N]
     long long B, first_frame;
     int N;
     double sigma, T;
     uint64_t seed;
 };
 
-// all-zero codeword -> every symbol is gray[0] on both rails = level 2*0-3 = -3 (QAM_modulator.cpp:127-139);
-// received = symbol + sigmaQAM*g (fresh per frame); LLR = -Demodulate(...) (bp_simulation.cpp:626-628).
-__global__ void __launch_bounds__(256) awgn_qam16_llr_kernel(const Qam16Args a) {
-    const int ns = a.N >> 2;
+// all-zero codeword -> every symbol is gray[0] on both rails = level 2*0 - (SQ-1) (QAM_modulator.cpp:127-139); the tail of
+// the last symbol is padded with zero bits (bp_simulation.cpp:575); received = symbol + sigmaQAM*g (fresh per frame);
+// LLR = -Demodulate(...) (bp_simulation.cpp:626-628).  H = bits per rail: 2 (16-QAM), 3 (64-QAM), 4 (256-QAM).
+template <int H>
+__global__ void __launch_bounds__(256) awgn_qam_llr_kernel(const QamArgs a) {
+    constexpr int m = 2 * H;
+    const int ns = (a.N + m - 1) / m;
     const long long total = a.B * (long long)ns;
     const double N0 = 2.0 * a.sigma * a.sigma;
+    const double corner = -(double)((1 << H) - 1);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const long long b = i / ns;
         const int s = (int)(i - b * ns);
         double g0, g1;
         gauss_pair(a.seed, (uint64_t)(a.first_frame + b), (uint32_t)s, 1u, g0, g1);
-        const double xi = -3.0 + a.sigma * g0, xq = -3.0 + a.sigma * g1;
-        double b0, b1, b2, b3;
-        demod_rail16(xi, N0, a.T, 0, b0, b1);
-        demod_rail16(xq, N0, a.T, 0, b2, b3);
-        double *o = a.llr + b * (long long)a.N + 4 * s;
-        *reinterpret_cast<double2 *>(o) = make_double2(-b0, -b1);
-        *reinterpret_cast<double2 *>(o + 2) = make_double2(-b2, -b3);
+        double bit[m], bi[H], bq[H];
+        demod_rail<H>(corner + a.sigma * g0, N0, a.T, 0, bi);
+        demod_rail<H>(corner + a.sigma * g1, N0, a.T, 0, bq);
+#pragma unroll
+        for (int h = 0; h < H; ++h) { bit[h] = -bi[h]; bit[H + h] = -bq[h]; }
+        double *o = a.llr + b * (long long)a.N + (long long)m * s;
+        if (m * s + m <= a.N && (a.N & 1) == 0) {
+#pragma unroll
+            for (int h = 0; h < m; h += 2) *reinterpret_cast<double2 *>(o + h) = make_double2(bit[h], bit[h + 1]);   // 16-byte aligned: N and m even
+        } else {
+#pragma unroll
+            for (int h = 0; h < m; ++h) if (m * s + h < a.N) o[h] = bit[h];
+        }
     }
 }
 
@@ -306,6 +316,26 @@ __global__ void __launch_bounds__(64) ims_coef_kernel(const ImsCoefArgs a) {
         __syncthreads();
     }
     if (f0 + lane < a.B) a.coef[f0 + lane] = sqrt((double)a.N / en);                    // :5481
+}
+
+// ---- interleaver application --------------------------------------------------------------------------------
+// out[b][i] = in[b][map[i]]  (Permutation(), direct_inverse_perm.cpp:785-900, with the per-mode index arithmetic folded into
+// one map by ldpc/interleaver.h).  Streaming gather: writes coalesced, reads scattered inside one frame (L2 resident).
+struct PermuteArgs {
+    const double *in;
+    double *out;
+    const int32_t *map;   // [N]
+    long long B;
+    int N;
+};
+
+__global__ void __launch_bounds__(256) permute_kernel(const PermuteArgs a) {
+    const long long total = a.B * (long long)a.N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / a.N;
+        const int v = (int)(i - b * a.N);
+        a.out[i] = a.in[b * a.N + a.map[v]];
+    }
 }
 
 }  // namespace ldpc

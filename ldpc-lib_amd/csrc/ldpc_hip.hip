@@ -2,6 +2,7 @@
 // launch geometry, workspaces, HIP-event timing.  No CPU decode path exists in this library: every entry
 // point either runs the HIP kernels or fails with a message.
 #include "../../include/ldpc_hip.h"
+#include "../../include/ldpc/interleaver.h"
 
 #include <hip/hip_runtime.h>
 
@@ -637,8 +638,8 @@ static int awgn_sigma(const ldpc_hip_ctx *c, double snr_db, int modulation_type,
     const double bitrate = (double)(cc - b) / (cc - punctured_blocks);  // bp_simulation.cpp:444
     if (modulation_type == 0) {
         *sigma = std::sqrt(std::pow(10, -snr_db / 10) / 2 / bitrate);    // :445
-    } else if (modulation_type == 1 || modulation_type == 2) {
-        const int QAM = modulation_type == 1 ? 4 : 16, halfmlog = modulation_type == 1 ? 1 : 2;
+    } else if (modulation_type >= 1 && modulation_type <= 4) {   // bp_simulation.cpp:402-411: QAM4, QAM16, QAM64, QAM256
+        const int QAM = 1 << (2 * modulation_type), halfmlog = modulation_type == 1 ? 1 : modulation_type;
         const double norm_factor = 2.0 * (QAM - 1.0) / 3.0;              // :447
         *sigma = std::sqrt(std::pow(10., -snr_db / 10.) / (2 * bitrate * halfmlog * 2) * norm_factor);  // :449
     } else {
@@ -667,21 +668,32 @@ int ldpc_hip_awgn_llr_dev(ldpc_hip_ctx *c, double snr_db, int modulation_type, i
     return 0;
 }
 
-int ldpc_hip_awgn_qam16_llr_dev(ldpc_hip_ctx *c, double snr_db, double T, uint64_t seed, long long first_frame,
-                                long long B, double *d_llr, void *stream_) {
-    if (!c || !d_llr || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_awgn_qam16_llr_dev: bad argument");
-    if (c->N % 4) return fail(LDPC_HIP_EUNSUPPORTED, "16-QAM needs N %% 4 == 0 (N=%d)", c->N);
+int ldpc_hip_awgn_qam_llr_dev(ldpc_hip_ctx *c, int modulation_type, double snr_db, double T, uint64_t seed, long long first_frame,
+                              long long B, double *d_llr, void *stream_) {
+    if (!c || !d_llr || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_awgn_qam_llr_dev: bad argument");
+    if (modulation_type < 2 || modulation_type > 4)
+        return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_awgn_qam_llr_dev: modulation_type %d (2 QAM16, 3 QAM64, 4 QAM256)", modulation_type);
     if (B == 0) return 0;
     if (int rc = set_device(c)) return rc;
-    ldpc::Qam16Args a{};
-    if (int rc = awgn_sigma(c, snr_db, 2, 0, &a.sigma)) return rc;
+    ldpc::QamArgs a{};
+    if (int rc = awgn_sigma(c, snr_db, modulation_type, 0, &a.sigma)) return rc;
     a.llr = d_llr; a.B = B; a.first_frame = first_frame; a.N = c->N; a.T = T; a.seed = seed;
-    const long long total = B * (long long)(c->N / 4);
+    const int m = 2 * modulation_type;
+    const long long total = B * (long long)((c->N + m - 1) / m);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(ldpc::awgn_qam16_llr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, a);
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (modulation_type == 2) hipLaunchKernelGGL(ldpc::awgn_qam_llr_kernel<2>, grid, block, 0, stream, a);
+    else if (modulation_type == 3) hipLaunchKernelGGL(ldpc::awgn_qam_llr_kernel<3>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(ldpc::awgn_qam_llr_kernel<4>, grid, block, 0, stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int ldpc_hip_awgn_qam16_llr_dev(ldpc_hip_ctx *c, double snr_db, double T, uint64_t seed, long long first_frame,
+                                long long B, double *d_llr, void *stream_) {
+    return ldpc_hip_awgn_qam_llr_dev(c, 2, snr_db, T, seed, first_frame, B, d_llr, stream_);
 }
 
 int ldpc_hip_qam_demod_dev(int Q, double T, double sigma, const double *d_x, long long ns, double *d_out,
@@ -696,6 +708,33 @@ int ldpc_hip_qam_demod_dev(int Q, double T, double sigma, const double *d_x, lon
     long long blocks = (ns + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(ldpc::qam_demod_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ldpc_hip_interleaver_build(int b, int c, int M, int halfmlog, int mode, int block_size, int step_size, const int16_t *hd,
+                               int32_t *direct, int32_t *inverse) {
+    if (!hd || !direct || !inverse) return fail(LDPC_HIP_EINVAL, "ldpc_hip_interleaver_build: null argument");
+    if (b <= 0 || c <= 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_interleaver_build: bad code shape");
+    std::vector<int> h((size_t)b * c);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = hd[i];
+    ldpc::Interleaver il;
+    std::string err;
+    if (!ldpc::build_interleaver(b, c, M, halfmlog, mode, block_size, step_size, h.data(), il, err)) return fail(LDPC_HIP_EUNSUPPORTED, "%s", err.c_str());
+    std::memcpy(direct, il.direct.data(), sizeof(int32_t) * il.direct.size());
+    std::memcpy(inverse, il.inverse.data(), sizeof(int32_t) * il.inverse.size());
+    return 0;
+}
+
+int ldpc_hip_permute_dev(const double *d_in, double *d_out, long long B, int N, const int32_t *d_map, int device, void *stream_) {
+    if (!d_in || !d_out || !d_map || B < 0 || N <= 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_permute_dev: bad argument");
+    if (d_in == d_out) return fail(LDPC_HIP_EINVAL, "ldpc_hip_permute_dev: in-place permutation is not supported");
+    if (B == 0) return 0;
+    HIP_TRY(hipSetDevice(device));
+    ldpc::PermuteArgs a{d_in, d_out, d_map, B, N};
+    long long blocks = (B * (long long)N + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(ldpc::permute_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -727,7 +766,7 @@ int ldpc_hip_simulate(ldpc_hip_ctx *c, double snr_db, int modulation_type, int p
     for (long long done = 0; done < B; done += chunk) {
         const long long nb = (B - done) < chunk ? (B - done) : chunk;
         int rc;
-        if (modulation_type == 2) rc = ldpc_hip_awgn_qam16_llr_dev(c, snr_db, 26.0, seed, first_frame + done, nb, c->w_llr, nullptr);
+        if (modulation_type >= 2) rc = ldpc_hip_awgn_qam_llr_dev(c, modulation_type, snr_db, 26.0, seed, first_frame + done, nb, c->w_llr, nullptr);
         else rc = ldpc_hip_awgn_llr_dev(c, snr_db, modulation_type, punctured_blocks, seed, first_frame + done, nb, c->w_llr, nullptr);
         if (rc) return rc;
         if ((rc = ldpc_hip_decode_dev(c, c->w_llr, nb, maxiter, alpha, c->w_hard, c->w_iters, nullptr, nullptr))) return rc;

@@ -43,10 +43,10 @@ extern "C" void orc_awgn_llr(unsigned int seed, int n_int01, double snr, double 
     }
 }
 
-extern "C" int orc_bp_simulation(int rh, int nh, const int *H, int M, int max_iterations, int n_frame_errors,
-                                 int n_experiments, double snr, double reference_frame_error,
-                                 int decoder_type, int modulation_type, int punctured_blocks,
-                                 unsigned int seed, orc_sim_result *out, int *iters_out) {
+extern "C" int orc_bp_simulation_perm(int rh, int nh, const int *H, int M, int max_iterations, int n_frame_errors,
+                                      int n_experiments, double snr, double reference_frame_error,
+                                      int decoder_type, int modulation_type, int punctured_blocks,
+                                      unsigned int seed, const int *inverse_map, orc_sim_result *out, int *iters_out) {
     if (!H || !out || rh <= 0 || nh <= rh || M <= 0) return -1;
     if (modulation_type != 0 && modulation_type != 1) return -2;  // QAM16+ wiring is broken upstream (Q5/Q6)
     const int b = rh, c = nh, r = b * M, n = c * M;
@@ -74,7 +74,7 @@ extern "C" int orc_bp_simulation(int rh, int nh, const int *H, int M, int max_it
     // itself is then overwritten with zeros (:568).
     for (int i = b * M; i < n; i++) (void)rng.next_int(0, 2);
 
-    std::vector<double> y(n), decword(n);
+    std::vector<double> y(n), decword(n), buffer(n);
     long long nse = 0, nue = 0, nde = 0, experiment = 0, sum_abs_iter = 0;
 
     while (nde < n_frame_errors && experiment <= n_experiments) {  // :591
@@ -82,8 +82,9 @@ extern "C" int orc_bp_simulation(int rh, int nh, const int *H, int M, int max_it
         const double sg = modulation_type == 0 ? sigma : sigmaQAM;
         for (int i = 0; i < n; ++i) {                              // :601-611
             double noise = rng.next_gaussian();
-            y[i] = -2.0 * (sg * noise + 2.0 * 0.0 - 1.0) / (sg * sg);
+            buffer[i] = -2.0 * (sg * noise + 2.0 * 0.0 - 1.0) / (sg * sg);
         }
+        for (int i = 0; i < n; ++i) y[i] = buffer[inverse_map ? inverse_map[i] : i];   // :684 Permutation(perm_state, 1, buffer, y)
         {                                                          // :699-709 puncturing
             const double init_val = out_type == 1 ? 0 : 0.5;
             const int plen = M * punctured_blocks, pstart = n - plen;
@@ -124,4 +125,12 @@ extern "C" int orc_bp_simulation(int rh, int nh, const int *H, int M, int max_it
     out->sum_abs_iter = sum_abs_iter;
     out->rng_next = (unsigned int)rng.gen();
     return 0;
+}
+
+extern "C" int orc_bp_simulation(int rh, int nh, const int *H, int M, int max_iterations, int n_frame_errors,
+                                 int n_experiments, double snr, double reference_frame_error,
+                                 int decoder_type, int modulation_type, int punctured_blocks,
+                                 unsigned int seed, orc_sim_result *out, int *iters_out) {
+    return orc_bp_simulation_perm(rh, nh, H, M, max_iterations, n_frame_errors, n_experiments, snr, reference_frame_error,
+                                  decoder_type, modulation_type, punctured_blocks, seed, nullptr, out, iters_out);
 }

@@ -36,6 +36,14 @@ int orc_bp_simulation(int rh, int nh, const int *H, int M, int max_iterations, i
                       int modulation_type, int punctured_blocks, unsigned int seed,
                       orc_sim_result *out, int *iters_out);
 
+/* Same with an interleaver between channel and decoder (bp_simulation.cpp:684): y[i] = buffer[inverse_map[i]];
+ * inverse_map = NULL is the identity (permutation_type 0).  The map itself comes from the compiled upstream code
+ * (tests/golden/interleavers.npz) or from the product's builder, which is checked against it. */
+int orc_bp_simulation_perm(int rh, int nh, const int *H, int M, int max_iterations, int n_frame_errors,
+                           int n_experiments, double snr, double reference_frame_error, int decoder_type,
+                           int modulation_type, int punctured_blocks, unsigned int seed, const int *inverse_map,
+                           orc_sim_result *out, int *iters_out);
+
 /* The reference's RNG contract (commons_portable.cpp:138-178) exposed for tests: seeds a private
  * std::mt19937, optionally burns n_int01 draws of next_random_int(0,2), then writes n Gaussians. */
 void orc_rng_gaussians(unsigned int seed, int n_int01, double *out, int n);

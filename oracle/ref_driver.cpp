@@ -1,7 +1,7 @@
 // ref_driver.cpp -- thin extern "C" driver around the UPSTREAM reference decoders.
 //
 // TEST INFRASTRUCTURE ONLY.  This file is our own code; it is compiled together with the reference's
-// own sources *where they lie* (/root/reference/{decoders,QAM_modulator,QAM_demodulator}.cpp, flags
+// own sources *where they lie* (/root/reference/{decoders,QAM_modulator,QAM_demodulator,direct_inverse_perm}.cpp, flags
 // -O3 -DSKIP_MEX as in the reference Makefile:20-21) into oracle/_ref/libldpc_ref.so by oracle/Makefile.
 // Nothing from the reference is copied into this repository and the .so never ships in git
 // (oracle/_ref/ is git-ignored).  It exists only in the build container; tests that need it skip
@@ -73,6 +73,29 @@ void ref_qam_demodulate(int Q, double T, double sigma, const double *x, int ns, 
     if (!st) return;
     Demodulate(st, const_cast<double *>(x), out);
     QAM_demodulator_close(st);
+}
+
+// Interleaver (direct_inverse_perm.cpp): the gather maps of both directions, read off by permuting the ramp 0..N-1.
+// hd row-major b x c.  Returns 0, or -1 when upstream refuses to open.
+int ref_perm_maps(int b, int c, int M, int QAM, int halfmlog, int mode, int block_size, int step_size, const short *hd,
+                  int *direct, int *inverse) {
+    PERMSTATE *st = Permutations_Open(b, c, M, QAM, halfmlog, mode, block_size, step_size);
+    if (!st) return -1;
+    short **rows = new short *[b];
+    for (int i = 0; i < b; i++) rows[i] = const_cast<short *>(hd) + (size_t)i * c;
+    Permutation_Init(st, rows);
+    const int N = c * M;
+    double *in = new double[N + N], *out = in + N;
+    for (int i = 0; i < N; i++) in[i] = i;
+    for (int dir = 0; dir < 2; dir++) {
+        for (int i = 0; i < N; i++) out[i] = -1;
+        Permutation(st, dir, in, out);
+        for (int i = 0; i < N; i++) (dir ? inverse : direct)[i] = (int)out[i];
+    }
+    delete[] in;
+    delete[] rows;
+    Permutations_Close(st);
+    return 0;
 }
 
 }  // extern "C"

@@ -12,7 +12,7 @@ from ldpc_testlib import (ASP_DEC, BP_DEC, GOLDEN_DIR, IMS_DEC, LMS_DEC, MS_DEC,
 pytestmark = pytest.mark.gpu
 
 DECODER_SETS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                      if os.path.basename(p).split("_")[0] in ("ms", "lms", "sp", "ims", "tasp"))
+                      if os.path.basename(p).split("_")[0] in ("ms", "lms", "sp", "ims", "tasp", "asp", "bp"))
 
 # sum-product soft values: exp() is ocml on the device and glibc in the reference (each within 1 ulp of the true
 # value, not identical to each other); every other operation is IEEE-exact and in the reference's order.  The 1-ulp
@@ -288,6 +288,26 @@ def test_qam_frontend(L, torch):
     x = torch.from_numpy(g[key + "_x"].reshape(-1, 2)).cuda()
     out = qam_demod(x, 4, 26.0, 0.8, 0).cpu().numpy().ravel()
     assert np.array_equal(out, g[key + "_llr"])
+    # device chain for 16 / 64 / 256-QAM (all-zero codeword at the constellation corner, Philox noise, demap, negate) against
+    # its CPU twin: numpy Philox + Box-Muller, the oracle's demapper.  N = 2048 is not a multiple of 6: the last 64-QAM symbol is
+    # padded (bp_simulation.cpp:575) and only its first two LLRs exist.
+    import ctypes as C
+    from ldpc_testlib import _as_double_p, oracle_lib, philox_gauss_pairs
+    H = relift(load_base_matrix(), 64)
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        for mod, Q, m, snr in ((2, 16, 4, 6.0), (3, 64, 6, 10.0), (4, 256, 8, 14.0)):
+            B, first, seed, N = 6, 987654321, (9 << 32) | 5, 2048
+            llr = dec.awgn_llr(snr, seed=seed, first_frame=first, B=B, modulation=mod).cpu().numpy()
+            ns = (N + m - 1) // m
+            rate, halfmlog = 0.5, m // 2
+            sigma = np.sqrt(10.0 ** (-snr / 10.0) / (2 * rate * halfmlog * 2) * (2.0 * (Q - 1.0) / 3.0))   # bp_simulation.cpp:447-449
+            g = philox_gauss_pairs(seed, first + np.arange(B), ns, tag=1)
+            x = np.ascontiguousarray(-(2 ** halfmlog - 1) + sigma * g)
+            ref = np.zeros((B, ns * m))
+            for b in range(B):
+                oracle_lib().orc_qam_demodulate(Q, 26.0, float(sigma), _as_double_p(x[b]), ns, _as_double_p(ref[b]), 0)
+            np.testing.assert_allclose(llr, -ref[:, :N], rtol=1e-9, atol=1e-9, err_msg=f"QAM-{Q}")
+            assert (llr > 0).mean() > 0.85      # zeros were sent
     # 16-QAM chain: statistics of the LLRs of the all-zero codeword + decodes at a reasonable Eb/N0
     H = relift(load_base_matrix(), 64)
     with L.LdpcHip(MS_DEC, H, 64) as dec:
@@ -554,3 +574,40 @@ def test_ldpc_sim_driver_reproduces_the_sequential_harness(L, tmp_path):
             assert fer[s] == res.fer and ber[s] == res.ber
             if survey_nde is not None:
                 assert res.nde == survey_nde
+
+
+@pytest.mark.parametrize("perm_type,block,inter", [(1, 128, 1), (2, 128, 1), (3, 300, 1), (4, 128, 16)])
+def test_exact_replay_harness_with_interleavers(L, torch, perm_type, block, inter):
+    """permutation_type 1-4: the harness applies upstream's inverse map between channel and decoder
+    (bp_simulation.cpp:684); counters, BER/FER and generator state equal the sequential restatement fed with the map recorded
+    from the compiled upstream interleaver.  Also the device gather itself against numpy."""
+    import ctypes as C
+    from ldpc_lib_amd.binding import build_interleaver, permute
+    from ldpc_testlib import SimResult, c_int_p, oracle_lib
+    lib = _compat_lib(L)
+    M = 64
+    H = np.ascontiguousarray(relift(load_base_matrix(), M), dtype=np.int32)
+    direct, inverse = build_interleaver(H, M, perm_type, 1, block, inter)     # == upstream's (tests/test_host_cpu.py)
+    out = (C.c_double * 7)()
+    nxt = C.c_uint()
+    lib.ldpc_bp_simulation_exact_perm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p, C.c_void_p]
+    assert lib.ldpc_bp_simulation_exact_perm(16, 32, H.ctypes.data, M, 50, 10**9, 400, 1.6, 1.0, MS_DEC, 0, perm_type, block, inter, 0, 7, 0,
+                                             C.addressof(out), C.addressof(nxt)) == 0
+    res = SimResult()
+    olib = oracle_lib()
+    olib.orc_bp_simulation_perm.argtypes = [C.c_int, C.c_int, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                            C.c_int, C.c_uint, c_int_p, C.c_void_p, C.c_void_p]
+    inv = np.ascontiguousarray(inverse, dtype=np.int32)
+    assert olib.orc_bp_simulation_perm(16, 32, H.ctypes.data_as(c_int_p), M, 50, 10**9, 400, 1.6, 1.0, MS_DEC, 0, 0, 7, inv.ctypes.data_as(c_int_p),
+                                       C.addressof(res), None) == 0
+    assert (out[2], out[3], out[4], out[5], out[6]) == (res.nse, res.nde, res.nue, res.experiment, res.sum_abs_iter)
+    assert out[0] == res.ber and out[1] == res.fer and nxt.value == res.rng_next
+    ident = SimResult()
+    assert olib.orc_bp_simulation_perm(16, 32, H.ctypes.data_as(c_int_p), M, 50, 10**9, 400, 1.6, 1.0, MS_DEC, 0, 0, 7, None, C.addressof(ident), None) == 0
+    assert ident.sum_abs_iter != res.sum_abs_iter      # the interleaver moved the noise around (same statistics, other frames)
+    x = torch.randn(37, 2048, dtype=torch.float64, device="cuda")
+    for m in (direct, inverse):
+        y = permute(x, torch.from_numpy(m).cuda())
+        assert torch.equal(y.cpu(), x.cpu()[:, torch.from_numpy(m.astype(np.int64))])
+    assert torch.equal(permute(permute(x, torch.from_numpy(direct).cuda()), torch.from_numpy(inverse).cuda()), x)

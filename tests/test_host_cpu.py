@@ -9,6 +9,8 @@ import sys
 import numpy as np
 import pytest
 
+from ldpc_testlib import GOLDEN_DIR, load_base_matrix, ref_lib, relift
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -236,3 +238,42 @@ def test_example_scenario_is_well_formed():
     from ldpc_testlib import load_base_matrix
     cells = [int(x) for x in get("results/0/code").replace("matrix (16 32) {", "").replace("}", "").split()]
     assert np.array_equal(np.array(cells).reshape(16, 32), load_base_matrix())
+
+
+def test_interleaver_maps_equal_upstreams():
+    """ldpc/interleaver.h (through the C-ABI, host only) against the maps recorded from the compiled upstream interleaver
+    (oracle/make_perm_goldens.py): identity, random, deterministic (all four halfmlog values, block-column counts that are and
+    are not multiples of halfmlog), block random with a short tail, interleaved random."""
+    import ldpc_lib_amd  # noqa: F401
+    from ldpc_lib_amd.binding import LdpcHipError, build_interleaver
+    g = np.load(os.path.join(GOLDEN_DIR, "interleavers.npz"))
+    keys = sorted(k[:-4] for k in g.files if k.endswith("_cfg"))
+    assert len(keys) >= 200
+    modes = set()
+    for k in keys:
+        M, h, mode, bs, st = (int(x) for x in g[k + "_cfg"])
+        d, i = build_interleaver(g[k + "_H"], M, mode, h, bs, st)
+        assert np.array_equal(d, g[k + "_direct"]) and np.array_equal(i, g[k + "_inverse"]), (k, M, h, mode, bs, st)
+        assert np.array_equal(d[i], np.arange(d.size))          # the two directions undo each other
+        modes.add((mode, h))
+    assert {(m, h) for m in range(5) for h in (1, 2, 3, 4)} <= modes
+    H = g[keys[0] + "_H"]
+    with pytest.raises(LdpcHipError):
+        build_interleaver(H, 8, 4, 1, 0, 5)      # step that does not divide N: upstream leaves positions unwritten -> rejected
+    with pytest.raises(LdpcHipError):
+        build_interleaver(H, 8, 7, 1)            # unknown permutation type
+
+
+@pytest.mark.skipif(ref_lib() is None, reason="oracle/_ref not built (needs the upstream tree)")
+def test_interleaver_maps_against_the_compiled_reference_beyond_the_fixture():
+    import ctypes as C
+    import ldpc_lib_amd  # noqa: F401
+    from ldpc_lib_amd.binding import build_interleaver
+    H = np.ascontiguousarray(relift(load_base_matrix(), 64), dtype=np.int16)
+    for h, mode, bs, st in ((1, 1, 0, 0), (2, 2, 0, 0), (3, 2, 0, 0), (4, 2, 0, 0), (1, 3, 128, 0), (1, 3, 300, 0), (1, 4, 0, 1), (2, 4, 0, 16)):
+        d = np.zeros(2048, dtype=np.int32)
+        i = np.zeros(2048, dtype=np.int32)
+        assert ref_lib().ref_perm_maps(16, 32, 64, 1 << (2 * h), h, mode, bs, st, H.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                                       i.ctypes.data_as(C.c_void_p)) == 0
+        dd, ii = build_interleaver(H, 64, mode, h, bs, st)
+        assert np.array_equal(d, dd) and np.array_equal(i, ii), (h, mode, bs, st)
