@@ -60,7 +60,7 @@ out = [
 ]
 # front-end kernels alone
 with L.LdpcHip(L.DEC_MS, L.relift_base_matrix(H0, 64), 64) as dec:
-    for mod, nm in ((0, "awgn_llr_kernel BPSK"), (2, "awgn_qam16_llr_kernel")):
+    for mod, nm in ((0, "awgn_llr_kernel BPSK"), (2, "awgn_qam_llr_kernel<2> 16-QAM"), (3, "awgn_qam_llr_kernel<3> 64-QAM"), (4, "awgn_qam_llr_kernel<4> 256-QAM")):
         buf = dec.awgn_llr(2.0, 1, 0, 65536, modulation=mod)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
