@@ -305,14 +305,17 @@ __global__ void __launch_bounds__(64) ims_coef_kernel(const ImsCoefArgs a) {
     double en = 0;
     for (int c0 = 0; c0 < a.N; c0 += 64) {
         const int i = c0 + lane;
-#pragma unroll 8
-        for (int f = 0; f < 64; ++f) {
+        double v[64];
+#pragma unroll
+        for (int f = 0; f < 64; ++f) {          // 64 coalesced 512-byte rows in flight per wave: the kernel is a pure HBM stream
             const long long fr = f0 + f;
-            tile[f * 65 + lane] = (fr < a.B && i < a.N) ? a.llr[fr * a.N + i] : 0.0;   // + 0*0 leaves the sum untouched
+            v[f] = (fr < a.B && i < a.N) ? a.llr[fr * a.N + i] : 0.0;   // + 0*0 leaves the sum untouched
         }
+#pragma unroll
+        for (int f = 0; f < 64; ++f) tile[f * 65 + lane] = v[f];
         __syncthreads();
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j) { const double v = tile[lane * 65 + j]; en += v * v; }
+#pragma unroll 16
+        for (int j = 0; j < 64; ++j) { const double x = tile[lane * 65 + j]; en += x * x; }
         __syncthreads();
     }
     if (f0 + lane < a.B) a.coef[f0 + lane] = sqrt((double)a.N / en);                    // :5481

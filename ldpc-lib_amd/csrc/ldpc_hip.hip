@@ -263,13 +263,13 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
     }
     case LDPC_HIP_SP_DEC: {
         const size_t lds = ldpc::sp_lds_bytes(t.ne, M, t.rh * M, N);
-        if (M % 64 == 0 && lds <= 160 * 1024) { p.body = "sp_body"; p.threads = 512; p.lds = lds; }
+        if (M >= 48 && lds <= 160 * 1024) { p.body = "sp_body"; p.threads = 512; p.lds = lds; }
         break;
     }
     case LDPC_HIP_BP_DEC: {
         p.required = true;  // code-specialised instances only
-        const size_t lds = (sizeof(double) + 1) * ((size_t)t.ne * M + (size_t)t.rh * M) + (((size_t)N + 15) & ~(size_t)15) + 16;
-        if (M % 64 == 0 && lds <= 160 * 1024) { p.body = "bp_body"; p.threads = 512; p.lds = lds; }
+        const size_t lds = ((((sizeof(double) + 1) * ((size_t)t.ne * M + (size_t)t.rh * M) + (size_t)N) + 15) & ~(size_t)15) + 16;
+        if (lds <= 160 * 1024) { p.body = "bp_body"; p.threads = 512; p.lds = lds; }
         break;
     }
     case LDPC_HIP_ASP_DEC: {
@@ -277,7 +277,7 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
         const size_t lds = sizeof(double) * (size_t)t.ne * M + (((size_t)N + 15) & ~(size_t)15) + 16;
         bool all_cw2 = true;
         for (int k = 0; k < t.nh; ++k) all_cw2 = all_cw2 && (t.col_start[k + 1] - t.col_start[k] == 2);
-        if (M % 64 == 0 && t.min_rw >= 2 && !all_cw2 && lds <= 160 * 1024) { p.body = "asp_body"; p.threads = 512; p.lds = lds; }
+        if (t.min_rw >= 2 && !all_cw2 && lds <= 160 * 1024) { p.body = "asp_body"; p.threads = 512; p.lds = lds; }
         break;
     }
     case LDPC_HIP_TASP_DEC:
@@ -319,7 +319,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
     c->decoder_id = decoder_id; c->device = device;
     c->rh = rh; c->nh = nh; c->M = M; c->N = nh * M; c->R = rh * M; c->ne = t.ne;
     c->hard_words = (c->N + 31) / 32;
-    c->bp_carry.assign((size_t)(c->R + 31) / 32, 0u);
+    c->bp_carry.assign((size_t)rh * ((M + 63) / 64) * 2, 0u);
     const char *venv = getenv("LDPC_HIP_MS_VARIANT");
     c->variant = venv ? atoi(venv) : 2;
 
@@ -494,7 +494,7 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
             // pass 1 with zero stale syndromes (frame 0: the carry); then re-decode only the frames that follow a
             // failed frame, with stale[b] = synd[b-1], and repeat for successors of frames whose outcome flipped.
             // This entry point therefore synchronises the stream for BP_DEC (it reads the iteration counts back).
-            const size_t sw = (size_t)c->R / 32;
+            const size_t sw = (size_t)c->rh * ((c->M + 63) / 64) * 2;   // u32 words per frame: one u64 per block row and 64-lane chunk
             if (B > c->bp_frames) {
                 if (c->d_bp_stale) (void)hipFree(c->d_bp_stale);
                 if (c->d_bp_synd) (void)hipFree(c->d_bp_synd);

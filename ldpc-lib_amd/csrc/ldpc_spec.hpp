@@ -35,8 +35,9 @@ struct SpecArgs {
     int maxiter;
     double alpha;
     // bp_body only (the other bodies ignore these and decode frame blockIdx.x):
-    const u32 *stale;     // [B][R/32] syndrome the previous call left behind (upstream's DEC_STATE::syndr), or null = zeros
-    u32 *synd_out;        // [B][R/32] syndrome this call leaves behind, or null
+    const u32 *stale;     // [B][RH*ceil(M/64)] u64 words (one per block row and 64-lane chunk, bit = lane): the syndrome the previous
+                          // call left behind (upstream's DEC_STATE::syndr), or null = zeros
+    u32 *synd_out;        // same layout: the syndrome this call leaves behind, or null
     const int *frame_idx; // [gridDim.x] frame decoded by each workgroup, or null = blockIdx.x
     // ims_body only: imin_sum_decod_qc_lm's quantiser (decoders.cpp:5445-5500)
     const double *ims_coef;   // [B] sqrt(N / sum y^2) per frame, from ims_coef_kernel (the sum is sequential: its rounding is part of the result)
@@ -543,14 +544,14 @@ constexpr int kSpWaves = 8;
 
 template <class C>
 struct SpView {  // column view of the code + static work split, all computed at compile time
-    static constexpr int CH = C::M / 64;                 // 64-lane chunks per circulant
+    static constexpr int CH = (C::M + 63) / 64;          // 64-lane chunks per circulant (the last one may be partly idle)
     int row_off[C::RH + 1] = {};                         // row-major edge id of (row j, slot 0)
     int cw[C::NH] = {};                                  // column weights
     int ce[C::NH][C::RH] = {};                           // edge ids of a column, rows ascending
     int cj[C::NH][C::RH] = {};                           // their block rows
     int cc[C::NH][C::RH] = {};                           // their shifts
-    int col_wave[C::NH * (C::M / 64)] = {};              // wave that owns unit (k, chunk)
-    int col_slot[C::NH * (C::M / 64)] = {};              // index of the unit inside its wave's list
+    int col_wave[C::NH * ((C::M + 63) / 64)] = {};       // wave that owns unit (k, chunk)
+    int col_slot[C::NH * ((C::M + 63) / 64)] = {};       // index of the unit inside its wave's list
     int units_max = 0;                                   // max units per wave
     int ne = 0;
     constexpr SpView() {
@@ -563,7 +564,7 @@ struct SpView {  // column view of the code + static work split, all computed at
                 ++cw[k];
             }
         int load[kSpWaves] = {}, cnt[kSpWaves] = {};
-        bool used[C::NH * (C::M / 64)] = {};
+        bool used[C::NH * ((C::M + 63) / 64)] = {};
         for (int it = 0; it < C::NH * CH; ++it) {         // heaviest remaining unit -> least loaded wave
             int best = -1;
             for (int u = 0; u < C::NH * CH; ++u)
@@ -578,9 +579,8 @@ struct SpView {  // column view of the code + static work split, all computed at
 
 template <class C>
 __device__ __forceinline__ void sp_body(const SpecArgs &a) {
-    static_assert(C::M % 64 == 0, "sp_body: lifting must be a multiple of 64");
     constexpr SpView<C> V{};
-    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, R = RH * M, CH = M / 64, T = kSpWaves * 64;
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, R = RH * M, CH = (M + 63) / 64, T = kSpWaves * 64;
     constexpr int NE = V.ne, UMAX = V.units_max;
     extern __shared__ double lds[];
     char *const zzb = reinterpret_cast<char *>(lds);                        // ZZ[e][t] at e*M*8 + t*8
@@ -589,6 +589,8 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
     int *const flag = reinterpret_cast<int *>(hb + ((N + 15) & ~15));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // lanes beyond the lifting in the last 64-lane chunk of a circulant sit out
+    auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
     const long long fr = blockIdx.x;
 
     auto mind = [](double x, double y) { return x < y ? x : y; };            // decoders.cpp:104
@@ -607,7 +609,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
         bool f = false;
         static_for<0, RH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
-            if (wave == u % kSpWaves) {
+            if (wave == u % kSpWaves && lane_ok(IC<ch>{})) {
                 const int n = ch * 64 + lane;
                 unsigned sy = 0;
                 static_for<0, C::RW[j]>([&](auto S) {
@@ -625,7 +627,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
     static_for<0, UMAX>([&](auto Q) { yd[decltype(Q)::value] = 1.0; sf[decltype(Q)::value] = 1.0; });
     static_for<0, NH * CH>([&](auto U) {
         constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
-        if (wave == V.col_wave[u]) {
+        if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
             const int t = ch * 64 + lane;
             const double yl = maxd(mind(a.llr[fr * N + k * M + t], 20.0), -20.0);   // :1949 INPUT_LIMIT
             yd[q] = sf[q] = exp(yl);
@@ -644,7 +646,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
         // ---- phase A
         static_for<0, NH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u], CW = V.cw[k];
-            if (wave == V.col_wave[u]) {
+            if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
                 const int t8 = (ch * 64 + lane) * 8;
                 double zo[CW];
                 static_for<0, CW>([&](auto X) {
@@ -665,7 +667,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
         // ---- phase B
         static_for<0, RH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
-            if (wave == u % kSpWaves) {
+            if (wave == u % kSpWaves && lane_ok(IC<ch>{})) {
                 const int n = ch * 64 + lane;
                 double s = 1.0;                                                       // :2010
                 static_for<0, C::RW[j]>([&](auto S) {
@@ -680,7 +682,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
         // ---- phase C
         static_for<0, NH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u], CW = V.cw[k];
-            if (wave == V.col_wave[u]) {
+            if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
                 const int t = ch * 64 + lane;
                 double soft = yd[q];                                                  // :2011
                 static_for<0, CW>([&](auto X) {
@@ -704,16 +706,16 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
 
     if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
     if (a.hard) {
-        for (int w = threadIdx.x; w < N / 32; w += T) {
+        for (int w = threadIdx.x; w < (N + 31) / 32; w += T) {
             u32 bits = 0;
-            for (int b = 0; b < 32; ++b) bits |= (u32)hb[32 * w + b] << b;
-            a.hard[fr * (N / 32) + w] = bits;
+            for (int b = 0; b < 32; ++b) if (32 * w + b < N) bits |= (u32)hb[32 * w + b] << b;
+            a.hard[fr * ((N + 31) / 32) + w] = bits;
         }
     }
     if (a.soft_out) {
         static_for<0, NH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
-            if (wave == V.col_wave[u]) a.soft_out[fr * N + k * M + ch * 64 + lane] = sf[q];
+            if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) a.soft_out[fr * N + k * M + ch * 64 + lane] = sf[q];
         });
     }
 }
@@ -872,9 +874,8 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
 // ---------------------------------------------------------------------------------------------------------------
 template <class C>
 __device__ __forceinline__ void asp_body(const SpecArgs &a) {
-    static_assert(C::M % 64 == 0, "asp_body: lifting must be a multiple of 64");
     constexpr SpView<C> V{};
-    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, CH = M / 64, T = kSpWaves * 64;
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, CH = (M + 63) / 64, T = kSpWaves * 64;
     constexpr int NE = V.ne, UMAX = V.units_max;
     extern __shared__ double lds[];
     char *const stb = reinterpret_cast<char *>(lds);                         // state[e][n] at e*M*8 + n*8
@@ -882,6 +883,8 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
     int *const flag = reinterpret_cast<int *>(hb + ((N + 15) & ~15));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // lanes beyond the lifting in the last 64-lane chunk of a circulant sit out
+    auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
     const long long fr = blockIdx.x;
 
     auto mind = [](double x, double y) { return x < y ? x : y; };
@@ -899,7 +902,7 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
         bool f = false;
         static_for<0, RH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
-            if (wave == u % kSpWaves) {
+            if (wave == u % kSpWaves && lane_ok(IC<ch>{})) {
                 const int n = ch * 64 + lane;
                 unsigned sy = 0;
                 static_for<0, C::RW[j]>([&](auto S) {
@@ -917,7 +920,7 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
     static_for<0, UMAX>([&](auto Q) { p1ch[decltype(Q)::value] = 0.5; so[decltype(Q)::value] = 0.5; });
     static_for<0, NH * CH>([&](auto U) {
         constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
-        if (wave == V.col_wave[u]) {
+        if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
             const int t = ch * 64 + lane;
             const double x = a.llr[fr * N + k * M + t] * 0.5;                 // :2351-2358
             const double y = maxd(mind(x, 20.0), -20.0);
@@ -942,7 +945,7 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
         static_for<0, RH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH, RW = C::RW[j];
             static_assert(RW >= 2, "asp_body: map_bin needs at least two edges per check");
-            if (wave == u % kSpWaves) {
+            if (wave == u % kSpWaves && lane_ok(IC<ch>{})) {
                 const int n8 = (ch * 64 + lane) * 8;
                 double P[RW], SF[RW], SB[RW];
                 static_for<0, RW>([&](auto S) {
@@ -965,7 +968,7 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
         // ---- phase 2: symbol nodes + local data update
         static_for<0, NH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u], CW = V.cw[k];
-            if (wave == V.col_wave[u]) {
+            if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
                 const int t = ch * 64 + lane;
                 double d[CW];
                 double P1 = p1ch[q], P0 = 1 - p1ch[q];                        // :2492-2496
@@ -997,16 +1000,16 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
 
     if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
     if (a.hard) {
-        for (int w = threadIdx.x; w < N / 32; w += T) {
+        for (int w = threadIdx.x; w < (N + 31) / 32; w += T) {
             u32 bits = 0;
-            for (int b = 0; b < 32; ++b) bits |= (u32)hb[32 * w + b] << b;
-            a.hard[fr * (N / 32) + w] = bits;
+            for (int b = 0; b < 32; ++b) if (32 * w + b < N) bits |= (u32)hb[32 * w + b] << b;
+            a.hard[fr * ((N + 31) / 32) + w] = bits;
         }
     }
     if (a.soft_out) {
         static_for<0, NH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
-            if (wave == V.col_wave[u]) a.soft_out[fr * N + k * M + ch * 64 + lane] = so[q];
+            if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) a.soft_out[fr * N + k * M + ch * 64 + lane] = so[q];
         });
     }
 }
@@ -1027,9 +1030,8 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
 // ---------------------------------------------------------------------------------------------------------------
 template <class C>
 __device__ __forceinline__ void bp_body(const SpecArgs &a) {
-    static_assert(C::M % 64 == 0, "bp_body: lifting must be a multiple of 64");
     constexpr SpView<C> V{};
-    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, R = RH * M, CH = M / 64, T = kSpWaves * 64;
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, R = RH * M, CH = (M + 63) / 64, T = kSpWaves * 64;
     constexpr int NE = V.ne, UMAX = V.units_max, RUMAX = (RH * CH + kSpWaves - 1) / kSpWaves;
     extern __shared__ double lds[];
     char *const zzb = reinterpret_cast<char *>(lds);                                  // ZZ[e][t] at e*M*8 + t*8
@@ -1037,9 +1039,12 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
     unsigned char *const bbb = reinterpret_cast<unsigned char *>(sb + (size_t)R * 8); // BB[e][t]
     unsigned char *const bsb = bbb + (size_t)NE * M;                                  // bs[j][n]
     unsigned char *const hb = bsb + R;                                                // [N] soft < 0
-    int *const flag = reinterpret_cast<int *>(hb + ((N + 15) & ~15));
+    constexpr size_t kFlagOff = (((size_t)(NE * M + R) * 9 + N) + 15) & ~(size_t)15;  // 16-byte aligned behind the byte arrays
+    int *const flag = reinterpret_cast<int *>(zzb + kFlagOff);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // lanes beyond the lifting in the last 64-lane chunk of a circulant sit out
+    auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
     const long long fr = a.frame_idx ? a.frame_idx[blockIdx.x] : (long long)blockIdx.x;
 
     auto mind = [](double x, double y) { return x < y ? x : y; };            // decoders.cpp:104
@@ -1059,10 +1064,10 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
         bool f = false;
         static_for<0, RH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
-            if (wave == u % kSpWaves) {
+            if (wave == u % kSpWaves && lane_ok(IC<ch>{})) {
                 const int n = ch * 64 + lane;
                 unsigned sy = 0;
-                if (with_stale && a.stale) sy = (a.stale[fr * (R / 32) + (j * M + n) / 32] >> (n & 31)) & 1u;
+                if (with_stale && a.stale) sy = (u32)(reinterpret_cast<const u64 *>(a.stale)[fr * (RH * CH) + u] >> lane) & 1u;
                 static_for<0, C::RW[j]>([&](auto S) {
                     constexpr int s = decltype(S)::value;
                     int t = n + C::SH[j][s]; if (t >= M) t -= M;
@@ -1079,7 +1084,7 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
     static_for<0, UMAX>([&](auto Q) { yd[decltype(Q)::value] = 0.0; so[decltype(Q)::value] = 0.0; });
     static_for<0, NH * CH>([&](auto U) {
         constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
-        if (wave == V.col_wave[u]) {
+        if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
             const int t = ch * 64 + lane;
             const double y = maxd(mind(a.llr[fr * N + k * M + t], 20.0), -20.0);   // :1738 INPUT_LIMIT
             yd[q] = so[q] = y;
@@ -1097,7 +1102,7 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
         // ---- A: variable-node activation
         static_for<0, NH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
-            if (wave == V.col_wave[u]) {
+            if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
                 const int t = ch * 64 + lane;
                 static_for<0, V.cw[k]>([&](auto X) {
                     constexpr int e = V.ce[k][decltype(X)::value];
@@ -1112,7 +1117,7 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
         // ---- A': check sums
         static_for<0, RH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
-            if (wave == u % kSpWaves) {
+            if (wave == u % kSpWaves && lane_ok(IC<ch>{})) {
                 const int n = ch * 64 + lane;
                 double s = 0.0;
                 unsigned bs = 0;
@@ -1130,7 +1135,7 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
         // ---- B: check-node activation seen from the variable, a-posteriori sums
         static_for<0, NH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
-            if (wave == V.col_wave[u]) {
+            if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
                 const int t = ch * 64 + lane;
                 double soft = yd[q];                                                  // :1834
                 static_for<0, V.cw[k]>([&](auto X) {
@@ -1158,20 +1163,20 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
     if (a.synd_out) {
         static_for<0, RH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value;
-            if (wave == u % kSpWaves && lane == 0) reinterpret_cast<u64 *>(a.synd_out + fr * (R / 32))[u] = left[u / kSpWaves];
+            if (wave == u % kSpWaves && lane == 0) reinterpret_cast<u64 *>(a.synd_out)[fr * (RH * CH) + u] = left[u / kSpWaves];
         });
     }
     if (a.hard) {
-        for (int w = threadIdx.x; w < N / 32; w += T) {
+        for (int w = threadIdx.x; w < (N + 31) / 32; w += T) {
             u32 bits = 0;
-            for (int b = 0; b < 32; ++b) bits |= (u32)hb[32 * w + b] << b;
-            a.hard[fr * (N / 32) + w] = bits;
+            for (int b = 0; b < 32; ++b) if (32 * w + b < N) bits |= (u32)hb[32 * w + b] << b;
+            a.hard[fr * ((N + 31) / 32) + w] = bits;
         }
     }
     if (a.soft_out) {
         static_for<0, NH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
-            if (wave == V.col_wave[u]) a.soft_out[fr * N + k * M + ch * 64 + lane] = so[q];
+            if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) a.soft_out[fr * N + k * M + ch * 64 + lane] = so[q];
         });
     }
 }

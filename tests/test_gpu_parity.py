@@ -94,8 +94,13 @@ def test_golden_vectors_host_api(L, name):
     (TASP_DEC, 200, (1.6,), 10, 15),            # hiprtc instance, 4 waves per frame
     (ASP_DEC, 64, (1.0, 1.6, 2.2), 120, 30),    # probability-domain flooding sum-product (decoder 2), ahead-of-time instance
     (ASP_DEC, 128, (1.7,), 20, 25),             # hiprtc instance, two 64-lane chunks per block row/column
+    (ASP_DEC, 126, (1.7,), 16, 25),             # the lifting of the shipped scenarios: last chunk 62 lanes
+    (ASP_DEC, 20, (3.0,), 60, 30),              # one partly idle chunk
     (BP_DEC, 64, (1.0, 1.6, 2.2), 120, 30),     # Gallager BP (decoder 0), ahead-of-time instance; failed frames chain into successors
     (BP_DEC, 128, (1.7,), 20, 25),              # hiprtc instance
+    (BP_DEC, 126, (1.4, 1.7), 24, 25),          # the lifting of the shipped scenarios; failed frames chain
+    (BP_DEC, 9, (2.5,), 80, 30),
+    (SP_DEC, 126, (1.7,), 16, 30),              # code-specialised sum-product for a lifting that is not a multiple of 64
 ])
 def test_random_batches_against_oracle(L, torch, dec_id, M, snrs, frames, maxiter):
     H = relift(load_base_matrix(), M)
@@ -168,7 +173,7 @@ def test_maxiter_one_and_unsupported_shapes(L):
     with L.LdpcHip(MS_DEC, H, 64) as dec, pytest.raises(L.LdpcHipError):
         dec.decode_host(llr, 0)  # maxiter < 1 is rejected, not guessed at
     with pytest.raises(L.LdpcHipError):
-        L.LdpcHip(ASP_DEC, relift(load_base_matrix(), 126), 126)  # ASP instances exist for M % 64 == 0 only: loud, no fallback
+        L.LdpcHip(ASP_DEC, relift(load_base_matrix(), 256), 256)  # per-edge state would not fit the 160 KiB LDS: loud, no fallback
     with pytest.raises(L.LdpcHipError):
         L.LdpcHip(6, H, 64)  # FHT_DEC (GF(q)) is out of scope: fails loudly, no fallback
     with pytest.raises(L.LdpcHipError):
