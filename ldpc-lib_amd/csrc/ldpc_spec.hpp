@@ -1204,6 +1204,10 @@ __device__ __forceinline__ int med3i(int x, int y, int z) {   // median of three
     return d;
 }
 
+#ifndef LDPC_IMS_MSG_COPIES
+#define LDPC_IMS_MSG_COPIES 1
+#endif
+
 template <class C>
 struct ColView {   // column view of the code, compile time
     int cw[C::NH] = {};
@@ -1225,8 +1229,10 @@ __device__ __forceinline__ void ims_body(const SpecArgs &a) {
     constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, W = (M + 63) / 64;
     extern __shared__ double lds[];
     char *const softb = reinterpret_cast<char *>(lds);                     // soft2[k][2M] int8
-    char *const msgb = softb + ((2 * N + 15) & ~15);                       // msg2[j][2][2M] dwords
-    int *const flag = reinterpret_cast<int *>(msgb + (size_t)RH * 2 * 2 * M * 4);
+    // MC copies of the message array: 2 = rotation by immediate offset (fewer VALU), 1 = half the LDS (more frames per CU)
+    constexpr int MC = LDPC_IMS_MSG_COPIES;
+    char *const msgb = softb + ((2 * N + 15) & ~15);                       // msg[j][2][MC*M] dwords
+    int *const flag = reinterpret_cast<int *>(msgb + (size_t)RH * 2 * MC * M * 4);
     const int n = threadIdx.x;
     const bool valid = (M % 64 == 0) || n < M;
     const int nv = valid ? n : 0;
@@ -1275,8 +1281,9 @@ __device__ __forceinline__ void ims_body(const SpecArgs &a) {
         if (valid) {
             static_for<0, 2>([&](auto Q) {
                 constexpr int q = decltype(Q)::value;
-                u32 *p = reinterpret_cast<u32 *>(msgb + ((size_t)(j * 2 + q) * 2 * M + nv) * 4);
-                p[0] = 0u; p[M] = 0u;
+                u32 *p = reinterpret_cast<u32 *>(msgb + ((size_t)(j * 2 + q) * MC * M + nv) * 4);
+                p[0] = 0u;
+                if constexpr (MC == 2) p[M] = 0u;
             });
         }
     });
@@ -1298,8 +1305,17 @@ __device__ __forceinline__ void ims_body(const SpecArgs &a) {
                     constexpr int k = decltype(K)::value;
                     static_for<0, V.cw[k]>([&](auto X) {
                         constexpr int x = decltype(X)::value, j = V.cj[k][x], s = V.cs[k][x], c = V.cc[k][x];
-                        constexpr int off = ((j * 2 + (s >> 2)) * 2 * M + (M - c) % M) * 4 + (s & 3);
-                        mv[g & 1][k % G][x] = (int)*reinterpret_cast<const signed char *>(msgb + off + nv * 4);
+                        if constexpr (MC == 2) {
+                            constexpr int off = ((j * 2 + (s >> 2)) * 2 * M + (M - c) % M) * 4 + (s & 3);
+                            mv[g & 1][k % G][x] = (int)*reinterpret_cast<const signed char *>(msgb + off + nv * 4);
+                        } else {
+                            constexpr int off = (j * 2 + (s >> 2)) * M * 4 + (s & 3), rot = (M - c) % M;
+                            u32 pos = (u32)nv + (u32)rot;                                     // (t - c) mod M
+                            if constexpr (rot == 0) {}
+                            else if constexpr ((M & (M - 1)) == 0) pos &= (u32)(M - 1);
+                            else pos = pos < pos - (u32)M ? pos : pos - (u32)M;              // unsigned min: pos - M wraps when pos < M
+                            mv[g & 1][k % G][x] = (int)*reinterpret_cast<const signed char *>(msgb + off + pos * 4);
+                        }
                     });
                 });
             };
@@ -1375,11 +1391,13 @@ __device__ __forceinline__ void ims_body(const SpecArgs &a) {
         if (valid) {                                                          // published after ALL rows have read soft2 (see above)
             static_for<0, RH>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                u32 *p0 = reinterpret_cast<u32 *>(msgb + ((size_t)(j * 2 + 0) * 2 * M + nv) * 4);
-                p0[0] = pm[j][0]; p0[M] = pm[j][0];
+                u32 *p0 = reinterpret_cast<u32 *>(msgb + ((size_t)(j * 2 + 0) * MC * M + nv) * 4);
+                p0[0] = pm[j][0];
+                if constexpr (MC == 2) p0[M] = pm[j][0];
                 if constexpr (C::RW[j] > 4) {
-                    u32 *p1 = reinterpret_cast<u32 *>(msgb + ((size_t)(j * 2 + 1) * 2 * M + nv) * 4);
-                    p1[0] = pm[j][1]; p1[M] = pm[j][1];
+                    u32 *p1 = reinterpret_cast<u32 *>(msgb + ((size_t)(j * 2 + 1) * MC * M + nv) * 4);
+                    p1[0] = pm[j][1];
+                    if constexpr (MC == 2) p1[M] = pm[j][1];
                 }
             });
         }
