@@ -86,6 +86,15 @@ __device__ __forceinline__ double sel64(double if0, double if1, mask64 m) {
     return mk(sel32(hi32(if0), hi32(if1), m), sel32(lo32(if0), lo32(if1), m));
 }
 
+// Upstream clamps with mind()/maxd() (decoders.cpp:104-105: a < b ? a : b and a < b ? b : a) or with `if (v < lo) v = lo`.
+// For a value that is not NaN and ordinary constant bounds v_min_f64 / v_max_f64 return the same double in ONE instruction;
+// the compare + select form is a v_cmp plus two v_cndmask_b32_e32 reading VCC, each with ~20 exposed cycles on gfx950
+// (tools/ubench_valu3.hip).  A NaN cannot reach these clamps: every operand is a finite LLR, a probability in [0,1] with a
+// strictly positive denominator, or the result of mind(.., finite) which already maps NaN to the bound.
+__device__ __forceinline__ double at_most(double x, double hi) { return fmin(x, hi); }
+__device__ __forceinline__ double at_least(double x, double lo) { return fmax(x, lo); }
+
+
 template <class C>
 __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
     static_assert(C::M == 64, "ms_m64_body: one frame per wavefront needs M == 64");
@@ -245,7 +254,7 @@ __device__ __forceinline__ void ms_body(const SpecArgs &a) {
         constexpr int c = decltype(S)::value;
         if constexpr (c == 0) return base;
         else if constexpr (POW2) return (base + 8u * (u32)c) & (u32)(8 * M - 1);
-        else { const u32 t = base + 8u * (u32)c; return t >= (u32)(8 * M) ? t - (u32)(8 * M) : t; }
+        else { const u32 t = base + 8u * (u32)c, w = t - (u32)(8 * M); return t < w ? t : w; }   // unsigned min: t - 8M wraps when t < 8M (no VCC select)
     };
     auto vote = [&](bool fail) -> bool {
         if constexpr (W == 1) return __ballot(fail) != 0ull;
@@ -403,7 +412,7 @@ __device__ __forceinline__ void lms_body(const SpecArgs &a) {
         constexpr int c = decltype(S)::value;
         if constexpr (c == 0) return base;
         else if constexpr (POW2) return (base + 8u * (u32)c) & (u32)(8 * M - 1);
-        else { const u32 t = base + 8u * (u32)c; return t >= (u32)(8 * M) ? t - (u32)(8 * M) : t; }
+        else { const u32 t = base + 8u * (u32)c, w = t - (u32)(8 * M); return t < w ? t : w; }   // unsigned min: t - 8M wraps when t < 8M (no VCC select)
     };
     auto vote = [&](bool fail) -> bool {  // does any check of the frame fail?
         if constexpr (W == 1) return __ballot(fail) != 0ull;
@@ -471,7 +480,7 @@ __device__ __forceinline__ void lms_body(const SpecArgs &a) {
                 tv[s] = tt;
                 nS = __builtin_amdgcn_alignbit(nS, hi32(tt), 31);   // sign kept even when the magnitude clips to 0 (:5164-5168)
                 double mag = fabs(tt) - beta;
-                mag = mag < 0 ? 0 : mag;
+                mag = at_least(mag, 0.0);                     // :5166-5167 `if (mag < 0) mag = 0`
                 const mask64 c1 = lanes_lt(mag, nm1);       // process_check_node :5012-5027
                 nm2 = fmin(fmax(mag, nm1), nm2);
                 npos = sel32(npos, (u32)s, c1);
@@ -593,8 +602,6 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
     auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
     const long long fr = blockIdx.x;
 
-    auto mind = [](double x, double y) { return x < y ? x : y; };            // decoders.cpp:104
-    auto maxd = [](double x, double y) { return x < y ? y : x; };            // decoders.cpp:105
     auto vote = [&](bool fail) -> bool {
         if (threadIdx.x == 0) *flag = 0;
         __syncthreads();
@@ -629,7 +636,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
         constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
         if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
             const int t = ch * 64 + lane;
-            const double yl = maxd(mind(a.llr[fr * N + k * M + t], 20.0), -20.0);   // :1949 INPUT_LIMIT
+            const double yl = at_least(at_most(a.llr[fr * N + k * M + t], 20.0), -20.0);   // :1949 INPUT_LIMIT
             yd[q] = sf[q] = exp(yl);
             hb[k * M + t] = yd[q] < 1.0;
             static_for<0, V.cw[k]>([&](auto X) {                                     // :1957-1959
@@ -691,7 +698,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
                     double *zp = reinterpret_cast<double *>(zzb + (size_t)V.ce[k][x] * M * 8 + t * 8);
                     double A = *reinterpret_cast<const double *>(sb + (size_t)(V.cj[k][x] * M + nn) * 8) / *zp;
                     A = (1 + A) / (1 - A);
-                    A = maxd(mind(A, 1.9e+8), -5.2e-9);                              // :2120 (negative lower clamp is upstream's)
+                    A = at_least(at_most(A, 1.9e+8), -5.2e-9);                        // :2120 (negative lower clamp is upstream's)
                     *zp = A;
                     soft *= A;
                 });
@@ -747,7 +754,7 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
         constexpr int c = decltype(S)::value;
         if constexpr (c == 0) return base;
         else if constexpr ((M & (M - 1)) == 0) return (base + 8u * (u32)c) & (u32)(8 * M - 1);
-        else { const u32 t = base + 8u * (u32)c; return t >= (u32)(8 * M) ? t - (u32)(8 * M) : t; }
+        else { const u32 t = base + 8u * (u32)c, w = t - (u32)(8 * M); return t < w ? t : w; }   // unsigned min: t - 8M wraps when t < 8M (no VCC select)
     };
     auto vote = [&](bool fail) -> bool {
         if constexpr (W == 1) return __ballot(fail) != 0ull;
@@ -775,14 +782,12 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
         });
         return valid && f;
     };
-    auto mind = [](double x, double y) { return x < y ? x : y; };
-    auto maxd = [](double x, double y) { return x < y ? y : x; };
 
     if (valid) {
         static_for<0, NH>([&](auto K) {                                     // :2611-2618
             constexpr int k = decltype(K)::value;
             const double x = a.llr[fr * N + k * M + n] * 0.5;
-            const double y = maxd(mind(x, 20.0), -20.0);
+            const double y = at_least(at_most(x, 20.0), -20.0);
             const double e0 = exp(y), e1 = exp(-y);
             *reinterpret_cast<double *>(ldsb + n8 + k * (8 * M)) = e1 / (e0 + e1);
         });
@@ -809,8 +814,7 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
                 const double x = *reinterpret_cast<const double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M));
                 const double aa = Z[j][s];
                 double v = x * (1.0 - aa) / (aa + x - 2.0 * aa * x);        // :2686 rho = gamma - lambda
-                if (v < TT) v = TT;                                          // :2694-2695
-                if (v > 1 - TT) v = 1 - TT;
+                v = at_most(at_least(v, TT), 1 - TT);                        // :2694-2695
                 y[s] = v;
                 P[s] = 1 - 2 * v;                                            // map_bin :2206
             });
@@ -824,8 +828,7 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
             static_for<0, RW>([&](auto S) {
                 constexpr int s = decltype(S)::value;
                 double v = q[s];
-                if (v < T) v = T;                                            // :2703-2704
-                if (v > 1.0 - T) v = 1.0 - T;
+                v = at_most(at_least(v, T), 1.0 - T);                        // :2703-2704
                 Z[j][s] = v;
                 const double g = y[s] * v / (1.0 - y[s] - v + 2 * y[s] * v);  // :2716 gamma = rho + lambda
                 if (valid) *reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M)) = g;
@@ -887,8 +890,6 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
     auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
     const long long fr = blockIdx.x;
 
-    auto mind = [](double x, double y) { return x < y ? x : y; };
-    auto maxd = [](double x, double y) { return x < y ? y : x; };
     auto vote = [&](bool fail) -> bool {
         if (threadIdx.x == 0) *flag = 0;
         __syncthreads();
@@ -923,7 +924,7 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
         if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
             const int t = ch * 64 + lane;
             const double x = a.llr[fr * N + k * M + t] * 0.5;                 // :2351-2358
-            const double y = maxd(mind(x, 20.0), -20.0);
+            const double y = at_least(at_most(x, 20.0), -20.0);
             const double e0 = exp(y), e1 = exp(-y);
             const double p = e1 / (e0 + e1);
             p1ch[q] = so[q] = p;
@@ -988,7 +989,7 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
                     const double p1 = sov / d[x];
                     const double p0 = (1 - sov) / (1 - d[x]);
                     const double dd = p1 / (p1 + p0);
-                    *reinterpret_cast<double *>(stb + (size_t)V.ce[k][x] * M * 8 + nn * 8) = maxd(mind(dd, 1.0 - 0.000001), 0.000001);
+                    *reinterpret_cast<double *>(stb + (size_t)V.ce[k][x] * M * 8 + nn * 8) = at_least(at_most(dd, 1.0 - 0.000001), 0.000001);
                 });
             }
         });
@@ -1047,8 +1048,6 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
     auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
     const long long fr = a.frame_idx ? a.frame_idx[blockIdx.x] : (long long)blockIdx.x;
 
-    auto mind = [](double x, double y) { return x < y ? x : y; };            // decoders.cpp:104
-    auto maxd = [](double x, double y) { return x < y ? y : x; };            // decoders.cpp:105
     auto vote = [&](bool fail) -> bool {
         if (threadIdx.x == 0) *flag = 0;
         __syncthreads();
@@ -1086,7 +1085,7 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
         constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
         if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
             const int t = ch * 64 + lane;
-            const double y = maxd(mind(a.llr[fr * N + k * M + t], 20.0), -20.0);   // :1738 INPUT_LIMIT
+            const double y = at_least(at_most(a.llr[fr * N + k * M + t], 20.0), -20.0);   // :1738 INPUT_LIMIT
             yd[q] = so[q] = y;
             hb[k * M + t] = y < 0;
             static_for<0, V.cw[k]>([&](auto X) {                                    // :1731-1733
@@ -1145,7 +1144,7 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
                     double A = exp(*reinterpret_cast<const double *>(sb + (size_t)(j * M + nn) * 8) - *z);
                     const int b = bsb[j * M + nn] ^ bbb[e * M + t];
                     A = (double)(1 - 2 * b) * log((1 + A) / (1 - A));
-                    const double zn = maxd(mind(A, 19.07), -19.07);
+                    const double zn = at_least(at_most(A, 19.07), -19.07);
                     *z = zn;
                     soft += zn;
                 });
