@@ -60,6 +60,7 @@ constexpr int kRWM = 16;   // max circulants per block row (edge-sign bits per r
     }
 LDPC_AOT_KERNEL(ms_spec_appendix_c_m64_kernel, ms_m64_body, CodeAppendixCM64, 64, 2)
 LDPC_AOT_KERNEL(ms_spec_appendix_c_m126_kernel, ms_body, CodeAppendixCM126, 128, 2)
+LDPC_AOT_KERNEL(ms_chunk_appendix_c_m126_kernel, ms_chunk_body, CodeAppendixCM126, 64, 1)
 LDPC_AOT_KERNEL(ms_spec_appendix_c_m512_kernel, ms_body, CodeAppendixCM512, 512, 2)
 LDPC_AOT_KERNEL(ims_spec_appendix_c_m64_kernel, ims_body, CodeAppendixCM64, 64, 3)
 LDPC_AOT_KERNEL(ims_spec_appendix_c_m126_kernel, ims_body, CodeAppendixCM126, 128, 2)
@@ -141,6 +142,7 @@ struct AotInstance {
 const AotInstance kAot[] = {
     {LDPC_HIP_MS_DEC, (const void *)ms_spec_appendix_c_m64_kernel, 64, "ms_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_MS_DEC, (const void *)ms_spec_appendix_c_m126_kernel, 128, "ms_spec_appendix_c_m126_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM126>},
+    {LDPC_HIP_MS_DEC, (const void *)ms_chunk_appendix_c_m126_kernel, 64, "ms_chunk_appendix_c_m126_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM126>},
     {LDPC_HIP_MS_DEC, (const void *)ms_spec_appendix_c_m512_kernel, 512, "ms_spec_appendix_c_m512_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM512>},
     {LDPC_HIP_IMS_DEC, (const void *)ims_spec_appendix_c_m64_kernel, 64, "ims_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_IMS_DEC, (const void *)ims_spec_appendix_c_m126_kernel, 128, "ims_spec_appendix_c_m126_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM126>},
@@ -251,6 +253,9 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
     switch (decoder_id) {
     case LDPC_HIP_MS_DEC:
         if (M == 64) { p.body = "ms_m64_body"; p.threads = 64; p.lds = sizeof(double) * (size_t)N; }
+        else if (M > 64 && M <= 128 && !(getenv("LDPC_HIP_MS_CHUNK") && atoi(getenv("LDPC_HIP_MS_CHUNK")) == 0)) {
+            p.body = "ms_chunk_body"; p.threads = 64; p.lds = sizeof(double) * (size_t)N;   // one wave, two 64-lane chunks, no barriers
+        }
         else if (M >= 48 && M <= 512 && soft_lds <= 160 * 1024) { p.body = "ms_body"; p.threads = 64 * W; p.lds = soft_lds; }
         break;
     case LDPC_HIP_LMS_DEC:

@@ -109,7 +109,7 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
     static std::map<std::string, Kernel> cache;
     const std::string code = code_struct(rows, nh, M);
     const bool eight_waves = std::string(body) == "sp_body" || std::string(body) == "asp_body" || std::string(body) == "bp_body";  // 8 waves per frame, 2 frames per CU
-    const int threads = eight_waves ? 512 : ((M + 63) / 64) * 64;
+    const int threads = eight_waves ? 512 : std::string(body) == "ms_chunk_body" ? 64 : ((M + 63) / 64) * 64;
     const std::string key = std::to_string(device) + "|" + body + "|" + code;
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
@@ -124,7 +124,7 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
     hs << hf.rdbuf();
     const std::string hdr = hs.str();
     const std::string src = "#include \"ldpc_spec.hpp\"\nnamespace {\n" + code +
-                            "}\nextern \"C\" __global__ void __launch_bounds__(" + std::to_string(threads) + (eight_waves ? ", 4" : std::string(body) == "tasp_body" ? ", 1" : ", 2") + ") spec_jit(const ldpc_spec::SpecArgs a) {\n"
+                            "}\nextern \"C\" __global__ void __launch_bounds__(" + std::to_string(threads) + (eight_waves ? ", 4" : (std::string(body) == "tasp_body" || std::string(body) == "ms_chunk_body") ? ", 1" : ", 2") + ") spec_jit(const ldpc_spec::SpecArgs a) {\n"
                             "    ldpc_spec::" + body + "<Code>(a);\n}\n";
     hiprtcProgram prog = nullptr;
     const char *hdr_src[] = {hdr.c_str()};

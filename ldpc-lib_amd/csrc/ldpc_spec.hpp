@@ -386,6 +386,173 @@ __device__ __forceinline__ void ms_body(const SpecArgs &a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Flooding min-sum for 64 < M <= 128 on ONE wavefront per frame: every lane owns the checks / variables n and n + 64 of
+// each circulant (two "chunks").  Same arithmetic and order as ms_body, but a single wave needs no workgroup barrier at
+// all -- ms_body synchronises its waves after every block row of STATE1 (the order of the fp64 adds into a variable is
+// part of the result), 20 barriers per iteration -- because LDS executes one wave's accesses in program order.  The two
+// chunks give the scheduler two independent instruction streams.  This is the kernel for upstream's shipped liftings
+// (126, 67).  Records of both chunks live in VGPRs (160), channel values are re-read per chunk in STATE2.
+// ---------------------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void ms_chunk_body(const SpecArgs &a) {
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, CH = (M + 63) / 64;
+    static_assert(M > 64 && CH == 2, "ms_chunk_body: 64 < M <= 128");
+    constexpr bool POW2 = (M & (M - 1)) == 0;
+    extern __shared__ double lds[];  // [N] soft / acc
+    char *const ldsb = reinterpret_cast<char *>(lds);
+    const int lane = threadIdx.x;
+    const double alpha = a.alpha;
+    const long long fr = blockIdx.x;
+    bool ok[CH];
+    u32 n8[CH];
+    static_for<0, CH>([&](auto Q) {
+        constexpr int ch = decltype(Q)::value;
+        ok[ch] = (64 * ch + 64 <= M) || (64 * ch + lane < M);
+        n8[ch] = (u32)(ok[ch] ? 64 * ch + lane : 0) * 8u;
+    });
+    auto rot = [&](u32 base, auto S) -> u32 {
+        constexpr int c = decltype(S)::value;
+        if constexpr (c == 0) return base;
+        else if constexpr (POW2) return (base + 8u * (u32)c) & (u32)(8 * M - 1);
+        else { const u32 t = base + 8u * (u32)c, w = t - (u32)(8 * M); return t < w ? t : w; }
+    };
+
+    double m1[CH][RH], m2[CH][RH];
+    u32 meta[CH][RH];
+    static_for<0, CH>([&](auto Q) {
+        static_for<0, RH>([&](auto J) {
+            constexpr int ch = decltype(Q)::value, j = decltype(J)::value;
+            m1[ch][j] = 0.0; m2[ch][j] = 0.0; meta[ch][j] = 0u;
+        });
+    });
+
+    int res = -a.maxiter;
+    for (int iter = 0; iter < a.maxiter; ++iter) {
+        // ---------------- STATE1: block rows ascending, both chunks of a row before the next row
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            static_for<0, CH>([&](auto Q) {
+                constexpr int ch = decltype(Q)::value;
+                u32 mt = meta[ch][j], nb = n8[ch];
+                asm volatile("" : "+v"(mt), "+v"(nb) :: "memory");
+                const u32 pos = mt >> 16;
+                u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - C::RW[j]);
+                static_for<0, C::RW[j]>([&](auto S) {
+                    constexpr int s = decltype(S)::value;
+                    const double aa = sel64(m1[ch][j], m2[ch][j], lanes_eq(pos, (u32)s));
+                    const double cv = signed_mag(aa, Wt);
+                    Wt = twice(Wt);
+                    double *p = reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M));
+                    if (ok[ch]) {
+                        if constexpr (C::FIRST[j][s]) *p = cv;                   // the column's first edge stores (both chunks: disjoint variables)
+                        else __hip_atomic_fetch_add(p, cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("" ::: "memory");
+        // ---------------- STATE2, one chunk at a time, channel values in groups of 8 (the next group is in flight while
+        // this one is used): keeps the transient registers at 32 next to the 160 of the two chunks' records
+        static_for<0, CH>([&](auto Q) {
+            constexpr int ch = decltype(Q)::value;
+            constexpr int G = 8, NG = (NH + G - 1) / G;
+            double y[2][G];
+            int yo = ok[ch] ? 64 * ch + lane : 0;
+            asm volatile("" : "+v"(yo));
+            auto request = [&](auto GI) {
+                constexpr int g = decltype(GI)::value;
+                static_for<g * G, (g * G + G < NH ? g * G + G : NH)>([&](auto K) { constexpr int k = decltype(K)::value; y[g & 1][k % G] = a.llr[fr * N + yo + k * M]; });
+            };
+            request(IC<0>{});
+            static_for<0, NG>([&](auto GI) {
+                constexpr int g = decltype(GI)::value;
+                if constexpr (g + 1 < NG) request(IC<g + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (ok[ch]) {
+                    static_for<g * G, (g * G + G < NH ? g * G + G : NH)>([&](auto K) {
+                        constexpr int k = decltype(K)::value;
+                        double *p = reinterpret_cast<double *>(ldsb + n8[ch] + k * (8 * M));
+                        const double pr = *p * alpha;
+                        *p = (y[g & 1][k % G] + 0.0) + pr;
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        asm volatile("" ::: "memory");
+        // ---------------- STATE3
+        u32 failw = 0;
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int RW = C::RW[j];
+            static_for<0, CH>([&](auto Q) {
+                constexpr int ch = decltype(Q)::value;
+                u32 mt = meta[ch][j];
+                asm volatile("" : "+v"(mt));
+                const u32 pos = mt >> 16;
+                u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - RW);
+                double a1 = m1[ch][j] * alpha, a2 = m2[ch][j] * alpha;
+                asm volatile("" : "+v"(a1), "+v"(a2));
+                double nm1 = kMaxVal, nm2 = kMaxVal;
+                u32 npos = 0, nS = 0, sy = 0;
+                u32 nb = n8[ch];
+                asm volatile("" : "+v"(nb));
+                double r[RW];
+                static_for<0, RW>([&](auto S) {
+                    constexpr int s = decltype(S)::value;
+                    r[s] = *reinterpret_cast<const double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M));
+                });
+                static_for<0, RW>([&](auto S) {
+                    constexpr int s = decltype(S)::value;
+                    sy ^= hi32(r[s]);
+                    const double aa = sel64(a1, a2, lanes_eq(pos, (u32)s));
+                    const double x = signed_mag(aa, Wt);
+                    Wt = twice(Wt);
+                    const double tt = r[s] - x;
+                    nS = __builtin_amdgcn_alignbit(nS, hi32(tt), 31);
+                    const double v = fabs(tt);
+                    const mask64 c1 = lanes_lt(v, nm1);
+                    nm2 = fmin(fmax(v, nm1), nm2);
+                    npos = sel32(npos, (u32)s, c1);
+                    nm1 = fmin(v, nm1);
+                });
+                failw |= ok[ch] ? sy : 0u;
+                m1[ch][j] = nm1; m2[ch][j] = nm2; meta[ch][j] = nS | (npos << 16);
+                asm volatile("" : "+v"(m1[ch][j]), "+v"(m2[ch][j]), "+v"(meta[ch][j]));
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("" ::: "memory");
+        if (__ballot((failw >> 31) != 0) == 0ull) { res = iter + 1; break; }
+    }
+
+    if (lane == 0 && a.iters) a.iters[fr] = res;
+    if (a.hard) {
+        constexpr int HW = (N + 31) / 32;
+        for (int w = lane; w < HW; w += 64) {
+            u32 bits = 0;
+            for (int b = 0; b < 32; ++b) {
+                const int v = 32 * w + b;
+                if (v < N) bits |= (*reinterpret_cast<const u32 *>(ldsb + (size_t)v * 8 + 4) >> 31) << b;
+            }
+            a.hard[fr * HW + w] = bits;
+        }
+    }
+    if (a.soft_out) {
+        static_for<0, CH>([&](auto Q) {
+            constexpr int ch = decltype(Q)::value;
+            if (ok[ch]) {
+                static_for<0, NH>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    a.soft_out[fr * N + k * M + 64 * ch + lane] = *reinterpret_cast<const double *>(ldsb + n8[ch] + k * (8 * M));
+                });
+            }
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Layered offset min-sum (upstream lmin_sum_decod_qc_lm, decoders.cpp:5064-5425, active branch :5106-5290 with
 // MY_VERSION; semantics SURVEY Appendix A.3), code-specialised like the flooding kernel above, for any lifting
 // M <= 512: one frame per workgroup of W = ceil(M/64) wavefronts, a-posteriori values in LDS (8 B per variable,

@@ -349,6 +349,27 @@ def test_every_min_sum_kernel_tier_is_bit_exact(L, torch, monkeypatch, variant, 
         assert np.array_equal(soft.cpu().numpy(), s_ref)
 
 
+@pytest.mark.parametrize("chunk,expect", [("1", "ms_chunk_appendix_c_m126_kernel"), ("0", "ms_spec_appendix_c_m126_kernel")])
+def test_both_min_sum_kernels_for_the_shipped_lifting_are_bit_exact(L, monkeypatch, chunk, expect):
+    """M = 126 (upstream's shipped tailbite length): one wave owning two 64-lane chunks (default, no barriers) and two waves with
+    workgroup barriers produce the reference's bits, iteration counts and soft values."""
+    monkeypatch.setenv("LDPC_HIP_MS_CHUNK", chunk)
+    g = np.load(os.path.join(GOLDEN_DIR, "ms_m126_1p7.npz"))
+    with L.LdpcHip(MS_DEC, g["H"], 126) as dec:
+        assert expect in dec.kernel_name
+        d0, it0, _ = dec.decode_host(g["llr"], int(g["maxiter"]), decision=0)
+        assert np.array_equal(it0, g["iters"]) and np.array_equal(pack_bits(d0), g["hard"])
+        ns = g["soft"].shape[0]
+        d1, _, _ = dec.decode_host(g["llr"][:ns], int(g["maxiter"]), decision=1)
+        assert np.array_equal(d1, g["soft"])
+    H = relift(load_base_matrix(), 126)
+    llr = np.concatenate([awgn_llr(H, 126, s, 70 + i, 12) for i, s in enumerate((0.8, 1.6, 2.4))])
+    d_ref, it_ref, _ = Oracle(H, 126).decode(MS_DEC, llr, 50, 0)
+    with L.LdpcHip(MS_DEC, H, 126) as dec:
+        d, it, _ = dec.decode_host(llr, 50)
+        assert np.array_equal(it, it_ref) and np.array_equal(d, d_ref)
+
+
 def test_flagship_code_uses_the_ahead_of_time_instance(L):
     with L.LdpcHip(MS_DEC, relift(load_base_matrix(), 64), 64) as dec:
         assert "ahead of time" in dec.kernel_name
