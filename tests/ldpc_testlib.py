@@ -286,3 +286,23 @@ def unpack_bits(hard_words, N):
     w = np.ascontiguousarray(hard_words).view(np.uint32)
     bits = np.unpackbits(w.view(np.uint8).reshape(w.shape[0], -1), axis=1, bitorder="little")
     return bits[:, :N]
+
+
+def random_qc_code(rng, rh, nh, M, info_weight):
+    """A random protograph of the usual shape: dual-diagonal parity part (block columns 0..rh-1, shifts 0, one extra entry
+    closing the chain) and `info_weight[k]` random circulants in every information column."""
+    H = -np.ones((rh, nh), dtype=np.int16)
+    for j in range(rh):
+        H[j, j] = 0
+        if j + 1 < rh:
+            H[j + 1, j] = 0
+    H[0, rh - 1] = 1 % M
+    H[rh // 2, rh - 1] = 0 if H[rh // 2, rh - 1] < 0 else H[rh // 2, rh - 1]
+    for k in range(rh, nh):
+        rows = rng.choice(rh, size=min(rh, info_weight[(k - rh) % len(info_weight)]), replace=False)
+        for j in rows:
+            H[j, k] = rng.randint(0, M)
+    for j in range(rh):                      # every check sees at least two information columns
+        while (H[j, rh:] >= 0).sum() < 2:
+            H[j, rh + rng.randint(0, nh - rh)] = rng.randint(0, M)
+    return H

@@ -637,3 +637,35 @@ def test_exact_replay_harness_with_interleavers(L, torch, perm_type, block, inte
         y = permute(x, torch.from_numpy(m).cuda())
         assert torch.equal(y.cpu(), x.cpu()[:, torch.from_numpy(m.astype(np.int64))])
     assert torch.equal(permute(permute(x, torch.from_numpy(direct).cuda()), torch.from_numpy(inverse).cuda()), x)
+
+
+@pytest.mark.parametrize("rh,nh,M,weights,seed", [
+    (4, 8, 96, (3, 4, 2, 4), 1),          # small, dense rows (row weight up to 6), 2 waves' worth of lanes on one wave (chunk kernel)
+    (12, 24, 81, (3, 3, 6, 2, 11, 3), 2),  # 802.11n-like shape, lifting that is not a multiple of anything convenient
+    (8, 20, 128, (2, 3, 8, 3, 2), 3),      # power-of-two lifting above 64, high-rate
+])
+def test_every_decoder_on_random_protographs(L, torch, rh, nh, M, weights, seed):
+    """Codes the ahead-of-time instances know nothing about: every decoder compiles its own instance with hiprtc (or runs the
+    table kernel) and must reproduce the oracle -- bit for bit for MS / LMS / IMS, hard bits + iteration counts (soft values
+    to the stated tolerances) for the sum-product family."""
+    from ldpc_testlib import random_qc_code
+    rng = np.random.RandomState(seed)
+    H = random_qc_code(rng, rh, nh, M, weights)
+    assert (H >= 0).sum(axis=1).max() <= 16     # rows heavier than 8 circulants send integer min-sum to the table kernel
+    llr = np.concatenate([awgn_llr(H, M, s, 200 + i, 10) for i, s in enumerate((1.5, 3.0, 4.5))])
+    for dec_id in (MS_DEC, LMS_DEC, IMS_DEC, SP_DEC, ASP_DEC, TASP_DEC, BP_DEC):
+        o = Oracle(H, M)
+        d_ref, it_ref, _ = o.decode(dec_id, llr, 25, 0)
+        with L.LdpcHip(dec_id, H, M) as dec:
+            x = torch.from_numpy(llr).cuda()
+            hard, iters, soft = dec.decode(x, 25, want_soft=True)
+            torch.cuda.synchronize()
+            assert np.array_equal(iters.cpu().numpy(), it_ref), (dec_id, dec.kernel_name)
+            assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref)), (dec_id, dec.kernel_name)
+            s_ref, _, _ = Oracle(H, M).decode(dec_id, llr, 25, 1)
+            if dec_id in (MS_DEC, LMS_DEC, IMS_DEC):
+                assert np.array_equal(soft.cpu().numpy(), s_ref), (dec_id, dec.kernel_name)
+            elif dec_id == BP_DEC:
+                np.testing.assert_allclose(soft.cpu().numpy(), s_ref, rtol=BP_RTOL, atol=BP_ATOL)
+            else:
+                np.testing.assert_allclose(soft.cpu().numpy(), s_ref, rtol=SP_RTOL if dec_id == SP_DEC else TASP_RTOL)

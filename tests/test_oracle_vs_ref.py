@@ -41,3 +41,17 @@ def test_irregular_small_matrix():
         d1, i1, _ = o.decode(dec_id, llr, 30, 0)
         d2, i2, _ = r.decode(dec_id, llr, 30, 0)
         assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+
+
+@pytest.mark.parametrize("rh,nh,M,weights,seed", [(4, 8, 96, (3, 4, 2, 4), 1), (12, 24, 81, (3, 3, 6, 2, 11, 3), 2), (8, 20, 128, (2, 3, 8, 3, 2), 3),
+                                                   (6, 15, 30, (4, 2, 5), 4)])
+def test_restatement_equals_compiled_reference_on_random_protographs(rh, nh, M, weights, seed):
+    """Other code shapes than the example code (the same ones the GPU suite uses): every restated decoder against the compiled
+    upstream one."""
+    from ldpc_testlib import random_qc_code
+    H = random_qc_code(np.random.RandomState(seed), rh, nh, M, weights)
+    llr = np.concatenate([awgn_llr(H, M, s, 200 + i, 10) for i, s in enumerate((1.5, 3.0, 4.5))])
+    for dec_id in (MS_DEC, LMS_DEC, IMS_DEC, SP_DEC, ASP_DEC, TASP_DEC, BP_DEC):
+        d1, i1, a1 = Oracle(H, M).decode(dec_id, llr, 25, 0)
+        d2, i2, a2 = Reference(dec_id, H, M).decode(dec_id, llr, 25, 0)
+        assert np.array_equal(i1, i2) and np.array_equal(d1, d2, equal_nan=True) and np.array_equal(a1, a2, equal_nan=True), dec_id
