@@ -101,6 +101,7 @@ public:
         if (end == str.c_str() || *end) {                   // "1e5" and the like: go through double
             const double d = strtod(str.c_str(), &end);
             if (end == str.c_str() || *end) throw Error("jsonx: '" + str + "' is not a number");
+            if (!(d > -9.0e18 && d < 9.0e18)) throw Error("jsonx: '" + str + "' does not fit an integer");
             return (long long)d;
         }
         return v;
@@ -218,7 +219,12 @@ struct Reader {
         return {file, slash == std::string::npos ? std::string() : file.substr(0, slash)};
     }
 
+    int depth = 0;
+    struct DepthGuard { int &d; explicit DepthGuard(int &x) : d(x) { ++d; } ~DepthGuard() { --d; } };
+
     Value value(const std::string &ctx) {
+        DepthGuard guard(depth);
+        if (depth > 200) throw Error("jsonx: nesting deeper than 200 levels (" + ctx + ")");
         skip_ws();
         Value v;
         const int c = in.peek();
@@ -239,7 +245,7 @@ struct Reader {
                 const auto p = resolve(quoted(ctx));
                 std::ifstream f(p.first);
                 if (!f) throw Error("jsonx: cannot open '" + p.first + "' (" + ctx + ")");
-                Reader sub{f, p.second};
+                Reader sub{f, p.second, depth};
                 sub.skip_ws();
                 while (f.peek() != EOF) { v.items.push_back(sub.value(ctx + "/" + std::to_string(v.items.size()))); sub.skip_ws(); }
             }
@@ -259,6 +265,7 @@ struct Reader {
             skip_ws();
             expect("{", ctx);
             if (v.rows < 0 || v.cols < 0) throw Error("jsonx: negative matrix size (" + ctx + ")");
+            if ((long long)v.rows * v.cols > (1LL << 24)) throw Error("jsonx: matrix larger than 2^24 cells (" + ctx + ")");
             v.items.resize((size_t)v.rows * v.cols);
             if (!sparse) {
                 for (Value &cell : v.items) cell = value(ctx);
@@ -295,7 +302,7 @@ struct Reader {
             const auto p = resolve(quoted(ctx));
             std::ifstream f(p.first);
             if (!f) throw Error("jsonx: cannot open '" + p.first + "' (" + ctx + ")");
-            Reader sub{f, p.second};
+            Reader sub{f, p.second, depth};   // a file that includes itself runs into the depth limit
             return sub.value(ctx);
         }
         std::string num;
@@ -308,7 +315,7 @@ struct Reader {
 }  // namespace detail
 
 inline Value parse(std::istream &in, const std::string &dir = "") {
-    detail::Reader r{in, dir};
+    detail::Reader r{in, dir, 0};
     return r.value("");
 }
 inline Value parse_string(const std::string &text, const std::string &dir = "") {

@@ -277,3 +277,14 @@ def test_interleaver_maps_against_the_compiled_reference_beyond_the_fixture():
                                        i.ctypes.data_as(C.c_void_p)) == 0
         dd, ii = build_interleaver(H, 64, mode, h, bs, st)
         assert np.array_equal(d, dd) and np.array_equal(i, ii), (h, mode, bs, st)
+
+
+def test_host_headers_under_address_and_ub_sanitizers(tmp_path):
+    """jsonx reader/writer and interleaver maps with -fsanitize=address,undefined: malformed, mutated and hostile inputs end in
+    jsonx::Error / a refusal, never in a crash, an out-of-bounds access or undefined behaviour (tests/cpp/host_sanitize.cpp)."""
+    import subprocess
+    exe = str(tmp_path / "host_sanitize")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "host_sanitize.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
