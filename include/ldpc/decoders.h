@@ -51,13 +51,13 @@ void decod_close(DEC_STATE *st);
 int sum_prod_decod_qc_lm(DEC_STATE *st, double soft[], double decword[], int maxiter, int decision);
 int min_sum_decod_qc_lm(DEC_STATE *st, double soft[], double decword[], int maxiter, int decision, double alpha);
 int lmin_sum_decod_qc_lm(DEC_STATE *st, double soft[], double decword[], int maxiter, int decision, double alpha, double beta);
-/* present for link compatibility with upstream's dispatch (bp_simulation.cpp:716-729); not built: they die() */
-int bp_decod_qc_lm(DEC_STATE *st, double soft[], double decword[], int maxiter, int decision);
+int bp_decod_qc_lm(DEC_STATE *st, double soft[], double decword[], int maxiter, int decision);          /* keeps st's syndrome between calls like upstream */
 int sum_prod_gf2_decod_qc_lm(DEC_STATE *st, double soft[], double decword[], int maxiter, int decision);
 int imin_sum_decod_qc_lm(DEC_STATE *st, double soft[], double decword[], int maxiter, int decision, double alpha, double thr, int qbits, int dbits);
+int tdmp_sum_prod_gf2_decod_qc_lm(DEC_STATE *st, double soft[], double decword[], int maxiter, int decision);
+/* present for link compatibility with upstream's dispatch (bp_simulation.cpp:716-729); not built: they die() */
 int isum_prod_gf2_decod_qc_lm(DEC_STATE *st, double soft[], double decword[], int maxiter, int decision);
 int sum_prod_gfq_decod_lm(DEC_STATE *st, double *soft[], short *qhard, double *decword[], int maxiter, double p_thr);
-int tdmp_sum_prod_gf2_decod_qc_lm(DEC_STATE *st, double soft[], double decword[], int maxiter, int decision);
 int lche_decod(DEC_STATE *st, double soft[], double decword[], int maxiter, int decision);
 int encode_NBQCLDPC(DEC_STATE *st, int *msg);
 void left2right(short **matr, int nrow, int ncol);
