@@ -86,6 +86,25 @@ __device__ __forceinline__ double sel64(double if0, double if1, mask64 m) {
     return mk(sel32(hi32(if0), hi32(if1), m), sel32(lo32(if0), lo32(if1), m));
 }
 
+// Frame-wide "does any check fail?" for workgroups of several waves with ONE barrier: two flag words used alternately.  The
+// word a vote uses was cleared by thread 0 during the previous vote, after that vote's barrier (by then every wave has read
+// it for the vote before); every body has at least one more workgroup barrier before its next vote, which orders the clear
+// before the next atomicOr.  Bodies clear both words before their first barrier (vote_init).
+struct FrameVote {
+    int *flags;
+    int turn;
+    __device__ __forceinline__ void init(int *f) { flags = f; turn = 0; if (threadIdx.x == 0) { f[0] = 0; f[1] = 0; } }
+    __device__ __forceinline__ bool operator()(bool fail) {
+        int *f = flags + turn;
+        if (__ballot(fail) != 0ull && (threadIdx.x & 63) == 0) atomicOr(f, 1);
+        __syncthreads();
+        const bool r = *f != 0;
+        turn ^= 1;
+        if (threadIdx.x == 0) flags[turn] = 0;
+        return r;
+    }
+};
+
 // Upstream clamps with mind()/maxd() (decoders.cpp:104-105: a < b ? a : b and a < b ? b : a) or with `if (v < lo) v = lo`.
 // For a value that is not NaN and ordinary constant bounds v_min_f64 / v_max_f64 return the same double in ONE instruction;
 // the compare + select form is a v_cmp plus two v_cndmask_b32_e32 reading VCC, each with ~20 exposed cycles on gfx950
@@ -256,17 +275,11 @@ __device__ __forceinline__ void ms_body(const SpecArgs &a) {
         else if constexpr (POW2) return (base + 8u * (u32)c) & (u32)(8 * M - 1);
         else { const u32 t = base + 8u * (u32)c, w = t - (u32)(8 * M); return t < w ? t : w; }   // unsigned min: t - 8M wraps when t < 8M (no VCC select)
     };
+    FrameVote fvote;
+    if constexpr (W > 1) fvote.init(flag);
     auto vote = [&](bool fail) -> bool {
         if constexpr (W == 1) return __ballot(fail) != 0ull;
-        else {
-            if (threadIdx.x == 0) *flag = 0;
-            __syncthreads();
-            if (__ballot(fail) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
-            __syncthreads();
-            const bool r = *flag != 0;
-            __syncthreads();
-            return r;
-        }
+        else return fvote(fail);
     };
     const double *const yrow = a.llr + fr * N + (valid ? n : 0);
 
@@ -581,17 +594,11 @@ __device__ __forceinline__ void lms_body(const SpecArgs &a) {
         else if constexpr (POW2) return (base + 8u * (u32)c) & (u32)(8 * M - 1);
         else { const u32 t = base + 8u * (u32)c, w = t - (u32)(8 * M); return t < w ? t : w; }   // unsigned min: t - 8M wraps when t < 8M (no VCC select)
     };
-    auto vote = [&](bool fail) -> bool {  // does any check of the frame fail?
+    FrameVote fvote;
+    if constexpr (W > 1) fvote.init(flag);
+    auto vote = [&](bool fail) -> bool {
         if constexpr (W == 1) return __ballot(fail) != 0ull;
-        else {
-            if (threadIdx.x == 0) *flag = 0;
-            __syncthreads();
-            if (__ballot(fail) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
-            __syncthreads();
-            const bool r = *flag != 0;
-            __syncthreads();
-            return r;
-        }
+        else return fvote(fail);
     };
     // check_syndrome (decoders.cpp:793-814) of the current soft values
     auto syndrome_fail = [&]() -> bool {
@@ -769,15 +776,9 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
     auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
     const long long fr = blockIdx.x;
 
-    auto vote = [&](bool fail) -> bool {
-        if (threadIdx.x == 0) *flag = 0;
-        __syncthreads();
-        if (__ballot(fail) != 0ull && lane == 0) atomicOr(flag, 1);
-        __syncthreads();
-        const bool r = *flag != 0;
-        __syncthreads();
-        return r;
-    };
+    FrameVote fvote;
+    fvote.init(flag);
+    auto vote = [&](bool fail) -> bool { return fvote(fail); };
     // rows (x chunks) are dealt round-robin to the waves: unit (j, ch) -> wave (j*CH + ch) % 8
     auto syndrome_fail = [&]() -> bool {
         bool f = false;
@@ -923,17 +924,11 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
         else if constexpr ((M & (M - 1)) == 0) return (base + 8u * (u32)c) & (u32)(8 * M - 1);
         else { const u32 t = base + 8u * (u32)c, w = t - (u32)(8 * M); return t < w ? t : w; }   // unsigned min: t - 8M wraps when t < 8M (no VCC select)
     };
+    FrameVote fvote;
+    if constexpr (W > 1) fvote.init(flag);
     auto vote = [&](bool fail) -> bool {
         if constexpr (W == 1) return __ballot(fail) != 0ull;
-        else {
-            if (threadIdx.x == 0) *flag = 0;
-            __syncthreads();
-            if (__ballot(fail) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
-            __syncthreads();
-            const bool r = *flag != 0;
-            __syncthreads();
-            return r;
-        }
+        else return fvote(fail);
     };
     auto syndrome_fail = [&]() -> bool {                                    // check_syndrome_thr :2274-2306, thr 0.5
         bool f = false;
@@ -1057,15 +1052,9 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
     auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
     const long long fr = blockIdx.x;
 
-    auto vote = [&](bool fail) -> bool {
-        if (threadIdx.x == 0) *flag = 0;
-        __syncthreads();
-        if (__ballot(fail) != 0ull && lane == 0) atomicOr(flag, 1);
-        __syncthreads();
-        const bool r = *flag != 0;
-        __syncthreads();
-        return r;
-    };
+    FrameVote fvote;
+    fvote.init(flag);
+    auto vote = [&](bool fail) -> bool { return fvote(fail); };
     auto syndrome_fail = [&]() -> bool {
         bool f = false;
         static_for<0, RH * CH>([&](auto U) {
@@ -1215,15 +1204,9 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
     auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
     const long long fr = a.frame_idx ? a.frame_idx[blockIdx.x] : (long long)blockIdx.x;
 
-    auto vote = [&](bool fail) -> bool {
-        if (threadIdx.x == 0) *flag = 0;
-        __syncthreads();
-        if (__ballot(fail) != 0ull && lane == 0) atomicOr(flag, 1);
-        __syncthreads();
-        const bool r = *flag != 0;
-        __syncthreads();
-        return r;
-    };
+    FrameVote fvote;
+    fvote.init(flag);
+    auto vote = [&](bool fail) -> bool { return fvote(fail); };
     u64 left[RUMAX];   // syndrome bits of this wave's row units as last computed (what upstream leaves in st->syndr)
     static_for<0, RUMAX>([&](auto Q) { left[decltype(Q)::value] = 0ull; });
     auto syndrome_fail = [&](bool with_stale) -> bool {
@@ -1412,17 +1395,11 @@ __device__ __forceinline__ void ims_body(const SpecArgs &a) {
         else asm volatile("" ::: "memory");
     };
     auto sat = [&](int x) { return med3i(x, nmd, md); };   // limit_val :4308
+    FrameVote fvote;
+    if constexpr (W > 1) fvote.init(flag);
     auto vote = [&](bool fail) -> bool {
         if constexpr (W == 1) return __ballot(fail) != 0ull;
-        else {
-            if (threadIdx.x == 0) *flag = 0;
-            __syncthreads();
-            if (__ballot(fail) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
-            __syncthreads();
-            const bool r = *flag != 0;
-            __syncthreads();
-            return r;
-        }
+        else return fvote(fail);
     };
 
     int iy[NH];                                                             // :5472-5500 energy-normalised quantiser
