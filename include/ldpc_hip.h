@@ -130,6 +130,12 @@ int ldpc_hip_awgn_qam_llr_dev(ldpc_hip_ctx *ctx, int modulation_type, double snr
 int ldpc_hip_qam_demod_dev(int Q, double T, double sigma, const double *d_x, long long ns, double *d_out,
                            int out_type, int device, void *stream);
 
+/* Systematic encoder for the dual-diagonal QC-LDPC codes upstream's search produces (qc_encode / random_codeword,
+ * bp_simulation.cpp:22-191, with the information bits given instead of drawn).  HOST function.  info_bits: (nh-rh)*M bytes
+ * (0/1) for variable positions [rh*M, nh*M); codeword: nh*M bytes out, parity first.  Upstream's simulation never transmits
+ * the result (it zeroes the codeword, :568); this entry exists for callers that do and for the sign-symmetry tests. */
+int ldpc_hip_encode_host(int rh, int nh, int M, const int16_t *hd, const uint8_t *info_bits, uint8_t *codeword);
+
 /* Bit interleavers of the simulation chain (Permutations_Open / Permutation_Init / Permutation,
  * direct_inverse_perm.cpp:139-900; permutation_type of bp_simulation.h:21-23): mode 0 identity, 1 random, 2 deterministic,
  * 3 block random (block_size), 4 interleaved random (step_size); halfmlog = 1 (BPSK / QAM4), 2, 3, 4 (QAM16 / 64 / 256).

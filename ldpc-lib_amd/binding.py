@@ -87,6 +87,7 @@ def load_library():
     lib.ldpc_hip_simulate.argtypes = [vp, f64, i32, i32, i32, f64, u64, i64, i64, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.ldpc_hip_set_bp_chain.argtypes = [vp, i32, i32]
     lib.ldpc_hip_set_ims_params.argtypes = [vp, f64, i32, i32]
+    lib.ldpc_hip_encode_host.argtypes = [i32, i32, i32, vp, vp, vp]
     lib.ldpc_hip_interleaver_build.argtypes = [i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.ldpc_hip_permute_dev.argtypes = [vp, vp, i64, i32, vp, i32, vp]
     lib.ldpc_hip_profile_enable.argtypes = [vp, i32]
@@ -240,6 +241,19 @@ class LdpcHip:
         ms, n = C.c_double(), C.c_longlong()
         _check(self.lib, self.lib.ldpc_hip_profile_read(self.h, C.byref(ms), C.byref(n), 1 if reset else 0), "ldpc_hip_profile_read")
         return ms.value, n.value
+
+
+def encode(H, M, info_bits):
+    """Systematic QC-LDPC encoding on the host (upstream's qc_encode / random_codeword with given information bits):
+    info_bits uint8[(nh-rh)*M] -> codeword uint8[nh*M] (parity part first).  Needs no GPU."""
+    lib = load_library()
+    H = np.ascontiguousarray(H, dtype=np.int16)
+    rh, nh = H.shape
+    info = np.ascontiguousarray(info_bits, dtype=np.uint8)
+    assert info.size == (nh - rh) * M
+    cw = np.empty(nh * M, dtype=np.uint8)
+    _check(lib, lib.ldpc_hip_encode_host(rh, nh, int(M), H.ctypes.data, info.ctypes.data, cw.ctypes.data), "ldpc_hip_encode_host")
+    return cw
 
 
 def build_interleaver(H, M, mode, halfmlog=1, block_size=128, step_size=1):

@@ -3,6 +3,7 @@
 // point either runs the HIP kernels or fails with a message.
 #include "../../include/ldpc_hip.h"
 #include "../../include/ldpc/interleaver.h"
+#include "../../include/ldpc/encoder.h"
 
 #include <hip/hip_runtime.h>
 
@@ -714,6 +715,19 @@ int ldpc_hip_qam_demod_dev(int Q, double T, double sigma, const double *d_x, lon
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(ldpc::qam_demod_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, a);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ldpc_hip_encode_host(int rh, int nh, int M, const int16_t *hd, const uint8_t *info_bits, uint8_t *codeword) {
+    if (!hd || !info_bits || !codeword || rh <= 0 || nh <= rh || M <= 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_encode_host: bad argument");
+    std::vector<int> h((size_t)rh * nh);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = hd[i];
+    ldpc::BitVec cw;
+    const int rc = ldpc::encode(h.data(), rh, nh, M, info_bits, cw);
+    if (rc != 0)
+        return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_encode_host: this base matrix is not encodable by the dual-diagonal encoder (code %d: %s)", rc,
+                    rc < 0 ? "no positive shift in the special parity column" : "result is not a codeword");
+    std::memcpy(codeword, cw.data(), cw.size());
     return 0;
 }
 

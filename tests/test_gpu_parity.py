@@ -669,3 +669,40 @@ def test_every_decoder_on_random_protographs(L, torch, rh, nh, M, weights, seed)
                 np.testing.assert_allclose(soft.cpu().numpy(), s_ref, rtol=BP_RTOL, atol=BP_ATOL)
             else:
                 np.testing.assert_allclose(soft.cpu().numpy(), s_ref, rtol=SP_RTOL if dec_id == SP_DEC else TASP_RTOL)
+
+
+@pytest.mark.parametrize("M", [64, 126])
+def test_non_zero_codewords_decode_like_the_zero_codeword(L, torch, M):
+    """Upstream only ever sends the all-zero codeword (bp_simulation.cpp:568).  With the encoder the decoders can
+    be checked on real codewords: flipping the signs of the channel LLRs by a codeword c must flip the decisions by c and
+    leave the iteration counts alone.  For min-sum and layered min-sum that symmetry is EXACT in floating point (negation
+    commutes with every operation they use), so it is asserted bit for bit.  Integer min-sum is not mirror symmetric (an
+    a-posteriori value or message of exactly 0 -- frequent with 8-bit integers -- decides "0" whatever was sent) and the
+    sum-product family works on probabilities (p <-> 1-p does not mirror exactly): those are checked on converged frames."""
+    from ldpc_lib_amd.binding import encode
+    from ldpc_testlib import syndrome_np
+    H = relift(load_base_matrix(), M)
+    rng = np.random.RandomState(M)
+    B, K, N = 48, 16 * M, 32 * M
+    cws = np.stack([encode(H, M, rng.randint(0, 2, K).astype(np.uint8)) for _ in range(B)])
+    assert not syndrome_np(H, M, cws).any()
+    y0 = np.concatenate([awgn_llr(H, M, s, 300 + i, B // 3) for i, s in enumerate((1.4, 2.0, 3.0))])
+    y = y0 * (1.0 - 2.0 * cws)
+    for dec_id in (MS_DEC, LMS_DEC, IMS_DEC, SP_DEC, ASP_DEC, TASP_DEC, BP_DEC):
+        if dec_id in (ASP_DEC, BP_DEC) and M > 128:
+            continue
+        with L.LdpcHip(dec_id, H, M) as dec:
+            if dec_id == BP_DEC:
+                dec.set_bp_chain(False, True)
+            d0, it0, _ = dec.decode_host(y0.copy(), 30)
+            d1, it1, _ = dec.decode_host(y.copy(), 30)
+        if dec_id in (MS_DEC, LMS_DEC):
+            assert np.array_equal(it0, it1), dec_id
+            assert np.array_equal(d1.astype(np.uint8), d0.astype(np.uint8) ^ cws), dec_id
+        else:
+            conv = (it0 > 0) & (it1 > 0)
+            assert conv.sum() >= B // 3 and ((it0 > 0) != (it1 > 0)).sum() <= 2, dec_id
+            wrong = (d1[conv].astype(np.uint8) != cws[conv]).any(axis=1)             # converged, but to another codeword (undetected error)
+            assert wrong.sum() <= 2, dec_id
+            assert np.array_equal(wrong, (d0[conv] != 0).any(axis=1)) or wrong.sum() <= 1, dec_id   # ... and the zero-codeword run agrees on which
+            assert np.abs(it0[conv] - it1[conv]).max() <= 3, dec_id

@@ -288,3 +288,27 @@ def test_host_headers_under_address_and_ub_sanitizers(tmp_path):
                            os.path.join(ROOT, "tests", "cpp", "host_sanitize.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_encoder_returns_the_unique_systematic_codeword():
+    """include/ldpc/encoder.h through the C-ABI (host only): for the example code upstream's search produced, at several
+    liftings, the result is systematic, satisfies every parity check (checked with the independent numpy syndrome), is linear
+    in the information bits, and maps zero to zero.  A parity part the dual-diagonal encoder cannot solve is refused."""
+    import ldpc_lib_amd  # noqa: F401
+    from ldpc_lib_amd.binding import LdpcHipError, encode
+    from ldpc_testlib import syndrome_np
+    rng = np.random.RandomState(11)
+    for M in (1, 5, 64, 67, 126, 512):
+        H = relift(load_base_matrix(), M)
+        K = 16 * M
+        a, b = rng.randint(0, 2, K).astype(np.uint8), rng.randint(0, 2, K).astype(np.uint8)
+        ca, cb, cab = encode(H, M, a), encode(H, M, b), encode(H, M, a ^ b)
+        assert np.array_equal(ca[K:], a) and np.array_equal(cb[K:], b)
+        assert not syndrome_np(H, M, np.stack([ca, cb, cab])).any()
+        assert np.array_equal(ca ^ cb, cab)
+        assert not encode(H, M, np.zeros(K, dtype=np.uint8)).any()
+    bad = relift(load_base_matrix(), 8).copy()
+    bad[:, 15] = -1                       # no special parity column any more
+    bad[15, 15] = 0
+    with pytest.raises(LdpcHipError):
+        encode(bad, 8, np.ones(16 * 8, dtype=np.uint8))
