@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include "ldpc/encoder.h"
 #include "ldpc/interleaver.h"
 #include "ldpc/jsonx.h"
 
@@ -77,6 +78,33 @@ int main() {
             CHECK(!err.empty());
         }
     }
+    // ---- encoder: arbitrary base matrices either encode to a word that satisfies every check, or are refused
+    int encoded = 0;
+    for (int it = 0; it < 4000; ++it) {
+        const int b = 1 + (int)(rng() % 6), c = b + 1 + (int)(rng() % 8), M = 1 + (int)(rng() % 9);
+        std::vector<int> mx((size_t)b * c, -1);
+        const bool structured = (rng() % 2) != 0;
+        for (int i = 0; i < b; ++i)
+            for (int j = 0; j < c; ++j) {
+                if (structured && j < b) mx[(size_t)(i * c + j)] = (j == i || j + 1 == i) ? 0 : -1;      // dual diagonal
+                else mx[(size_t)(i * c + j)] = (rng() % 3) ? -1 : (int)(rng() % M);
+            }
+        if (structured && b > 1) { mx[(size_t)(b - 1)] = M > 1 ? 1 : 0; mx[(size_t)((b / 2) * c + b - 1)] = 0; }
+        std::vector<unsigned char> info((size_t)(c - b) * M + 64), cw;
+        for (auto &x : info) x = (unsigned char)(rng() & 1);
+        const int rc = ldpc::encode(mx.data(), b, c, M, info.data(), cw);
+        if (rc == 0) {
+            ++encoded;
+            for (int i = 0; i < b; ++i)
+                for (int h = 0; h < M; ++h) {
+                    unsigned char sy = 0;
+                    for (int j = 0; j < c; ++j)
+                        if (mx[(size_t)(i * c + j)] >= 0) sy ^= cw[(size_t)(j * M + (h + mx[(size_t)(i * c + j)]) % M)];
+                    CHECK(sy == 0);
+                }
+        }
+    }
+    CHECK(encoded > 100);
     printf("%s\n", failures ? "FAILED" : "ok");
     return failures ? 1 : 0;
 }
