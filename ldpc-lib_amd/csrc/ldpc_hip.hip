@@ -178,6 +178,7 @@ struct ldpc_hip_ctx {
     const void *spec_aot = nullptr;
     const ldpc_jit::Kernel *spec_jit = nullptr;
     int spec_threads = 64;
+    int spec_frames_per_block = 1;
     size_t spec_lds = 0;
     std::string kernel_name;  // what this context launches (ldpc_hip_kernel_name)
     std::string generic_name; // the table-driven kernel of this decoder, if one serves this code shape
@@ -244,7 +245,7 @@ int set_lds_limit(const void *kernel, size_t bytes) {
 }
 
 // Which code-specialised body serves this decoder / code shape, if any.  `required`: no generic kernel exists.
-struct SpecPlan { const char *body = nullptr; int threads = 0; size_t lds = 0; bool required = false; };
+struct SpecPlan { const char *body = nullptr; int threads = 0; size_t lds = 0; bool required = false; int frames_per_block = 1; };
 
 SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
     SpecPlan p;
@@ -254,6 +255,9 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
     switch (decoder_id) {
     case LDPC_HIP_MS_DEC:
         if (M == 64) { p.body = "ms_m64_body"; p.threads = 64; p.lds = sizeof(double) * (size_t)N; }
+        else if (M >= 8 && M <= 32) {   // several frames per wavefront (+30 % over the table kernel at M = 16..32; below 8 the table kernel wins)
+            p.body = "ms_small_body"; p.threads = 64; p.frames_per_block = 64 / M; p.lds = sizeof(double) * (size_t)N * (size_t)(64 / M);
+        }
         else if (M > 64 && M <= 128 && !(getenv("LDPC_HIP_MS_CHUNK") && atoi(getenv("LDPC_HIP_MS_CHUNK")) == 0)) {
             p.body = "ms_chunk_body"; p.threads = 64; p.lds = sizeof(double) * (size_t)N;   // one wave, two 64-lane chunks, no barriers
         }
@@ -370,7 +374,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
     const SpecPlan plan = plan_spec(decoder_id, t);
     std::string why_not = plan.body ? "" : "this code shape has no code-specialised kernel";
     if (plan.body && (c->variant >= 2 || plan.required)) {
-        c->spec_threads = plan.threads; c->spec_lds = plan.lds;
+        c->spec_threads = plan.threads; c->spec_lds = plan.lds; c->spec_frames_per_block = plan.frames_per_block;
         for (const AotInstance &inst : kAot)
             if (inst.decoder == decoder_id && inst.threads == plan.threads && (t.*inst.matches)()) {
                 c->spec_aot = inst.fn;
@@ -482,7 +486,9 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
             sa.ims_max_quant = (1 << (c->ims_qbits - 1)) - 1; sa.ims_max_data = (1 << (c->ims_dbits - 1)) - 1; sa.ims_ialpha = ims_ialpha;
         }
         sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
-        auto launch = [&](long long blocks) -> int {
+        sa.nframes = B;
+        auto launch = [&](long long frames) -> int {
+            const long long blocks = (frames + c->spec_frames_per_block - 1) / c->spec_frames_per_block;
             void *kargs[] = {&sa};
             if (c->spec_aot) {
                 if (int rc = set_lds_limit(c->spec_aot, c->spec_lds)) return rc;

@@ -43,6 +43,7 @@ struct SpecArgs {
     const double *ims_coef;   // [B] sqrt(N / sum y^2) per frame, from ims_coef_kernel (the sum is sequential: its rounding is part of the result)
     double ims_thr;
     int ims_max_quant, ims_max_data, ims_ialpha;
+    long long nframes;        // ms_small_body only: frames in the batch (several frames share a workgroup, the last one may be partly empty)
 };
 
 template <int I> struct IC { static constexpr int value = I; };
@@ -391,6 +392,145 @@ __device__ __forceinline__ void ms_body(const SpecArgs &a) {
         }
     }
     if (a.soft_out && valid) {
+        static_for<0, NH>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            a.soft_out[fr * N + k * M + n] = *reinterpret_cast<const double *>(ldsb + n8 + k * (8 * M));
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Flooding min-sum for SMALL liftings (M <= 32): F = floor(64 / M) frames share one wavefront, lane = f*M + n.
+// Same arithmetic and order as ms_m64_body per frame.  The frames of a wave converge at different iterations and upstream
+// stops a frame the moment its syndrome clears (its output comes from that very iteration), so a converged frame's lanes
+// freeze -- no more LDS writes, no record updates -- while the others go on; the wave ends when every frame has.
+// LDS: soft[f][N] fp64 (F*N*8 <= 16 KiB).
+// ---------------------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void ms_small_body(const SpecArgs &a) {
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, F = 64 / M;
+    static_assert(M <= 32 && F >= 2, "ms_small_body: M <= 32");
+    constexpr bool POW2 = (M & (M - 1)) == 0;
+    extern __shared__ double lds[];  // [F][N] soft / acc
+    const int lane = threadIdx.x;
+    const int f = lane / M, n = lane - f * M;
+    const long long fr = (long long)blockIdx.x * F + f;
+    const bool live = f < F && fr < a.nframes;             // lanes past F*M and frames past the batch sit out
+    char *const ldsb = reinterpret_cast<char *>(lds) + (size_t)(live ? f : 0) * N * 8;   // this lane's frame
+    const u32 n8 = (u32)n * 8u;
+    const double alpha = a.alpha;
+    const u64 frame_lanes = (M == 32 ? 0xffffffffull : ((1ull << M) - 1ull)) << ((live ? f : 0) * M);
+
+    auto rot = [&](u32 base, auto S) -> u32 {
+        constexpr int c = decltype(S)::value;
+        if constexpr (c == 0) return base;
+        else if constexpr (POW2) return (base + 8u * (u32)c) & (u32)(8 * M - 1);
+        else { const u32 t = base + 8u * (u32)c, w = t - (u32)(8 * M); return t < w ? t : w; }
+    };
+    const double *const yrow = a.llr + (live ? fr : 0) * N + n;
+
+    double m1[RH], m2[RH];
+    u32 meta[RH];
+    static_for<0, RH>([&](auto J) { constexpr int j = decltype(J)::value; m1[j] = 0.0; m2[j] = 0.0; meta[j] = 0u; });
+
+    bool done = !live;
+    int res = -a.maxiter;
+    for (int iter = 0; iter < a.maxiter; ++iter) {
+        double y[NH];
+        int yo = 0;
+        asm volatile("" : "+v"(yo));
+        static_for<0, NH>([&](auto K) { constexpr int k = decltype(K)::value; y[k] = yrow[yo + k * M]; });
+        // ---------------- STATE1
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            u32 mt = meta[j], nb = n8;
+            asm volatile("" : "+v"(mt), "+v"(nb));
+            const u32 pos = mt >> 16;
+            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - C::RW[j]);
+            static_for<0, C::RW[j]>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                const double aa = sel64(m1[j], m2[j], lanes_eq(pos, (u32)s));
+                const double cv = signed_mag(aa, Wt);
+                Wt = twice(Wt);
+                double *p = reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M));
+                if (!done) {
+                    if constexpr (C::FIRST[j][s]) *p = cv;
+                    else __hip_atomic_fetch_add(p, cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("" ::: "memory");
+        // ---------------- STATE2
+        if (!done) {
+            static_for<0, NH>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                double *p = reinterpret_cast<double *>(ldsb + n8 + k * (8 * M));
+                const double pr = *p * alpha;
+                *p = (y[k] + 0.0) + pr;
+                if constexpr (k % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        asm volatile("" ::: "memory");
+        // ---------------- STATE3
+        u32 failw = 0;
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int RW = C::RW[j];
+            u32 mt = meta[j];
+            asm volatile("" : "+v"(mt));
+            const u32 pos = mt >> 16;
+            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - RW);
+            double a1 = m1[j] * alpha, a2 = m2[j] * alpha;
+            asm volatile("" : "+v"(a1), "+v"(a2));
+            double nm1 = kMaxVal, nm2 = kMaxVal;
+            u32 npos = 0, nS = 0, sy = 0;
+            u32 nb = n8;
+            asm volatile("" : "+v"(nb));
+            double r[RW];
+            static_for<0, RW>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                r[s] = *reinterpret_cast<const double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M));
+            });
+            static_for<0, RW>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                sy ^= hi32(r[s]);
+                const double aa = sel64(a1, a2, lanes_eq(pos, (u32)s));
+                const double x = signed_mag(aa, Wt);
+                Wt = twice(Wt);
+                const double tt = r[s] - x;
+                nS = __builtin_amdgcn_alignbit(nS, hi32(tt), 31);
+                const double v = fabs(tt);
+                const mask64 c1 = lanes_lt(v, nm1);
+                nm2 = fmin(fmax(v, nm1), nm2);
+                npos = sel32(npos, (u32)s, c1);
+                nm1 = fmin(v, nm1);
+            });
+            failw |= sy;
+            if (!done) { m1[j] = nm1; m2[j] = nm2; meta[j] = nS | (npos << 16); }
+            asm volatile("" : "+v"(m1[j]), "+v"(m2[j]), "+v"(meta[j]));
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("" ::: "memory");
+        const u64 failing = __ballot(!done && (failw >> 31) != 0);          // per check, frames that are still running
+        if (!done && (failing & frame_lanes) == 0ull) { done = true; res = iter + 1; }   // :4761-4766, per frame
+        if (__ballot(!done) == 0ull) break;
+    }
+
+    if (!live) return;
+    if (n == 0 && a.iters) a.iters[fr] = res;
+    if (a.hard) {
+        constexpr int HW = (N + 31) / 32;
+        for (int w = n; w < HW; w += M) {
+            u32 bits = 0;
+            for (int b = 0; b < 32; ++b) {
+                const int v = 32 * w + b;
+                if (v < N) bits |= (*reinterpret_cast<const u32 *>(ldsb + (size_t)v * 8 + 4) >> 31) << b;
+            }
+            a.hard[fr * HW + w] = bits;
+        }
+    }
+    if (a.soft_out) {
         static_for<0, NH>([&](auto K) {
             constexpr int k = decltype(K)::value;
             a.soft_out[fr * N + k * M + n] = *reinterpret_cast<const double *>(ldsb + n8 + k * (8 * M));
