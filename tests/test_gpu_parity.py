@@ -219,6 +219,40 @@ def test_full_size_properties(L, torch):
         assert torch.equal(ia, ib) and torch.equal(ha ^ cw_words, hb)
 
 
+@pytest.mark.parametrize("dec_id,M,snr,B,maxiter,modulation", [
+    (SP_DEC, 64, 2.0, 32768, 50, 0),       # BASELINE config #3
+    (LMS_DEC, 512, 1.6, 4096, 50, 0),      # BASELINE config #4, one GPU's shard
+    (MS_DEC, 64, 5.0, 65536, 50, 2),       # BASELINE config #5: behind the 16-QAM soft demapper
+    (IMS_DEC, 64, 3.0, 65536, 50, 0),      # f1
+    (TASP_DEC, 126, 1.7, 16384, 15, 0),    # f2: the shipped scenario
+])
+def test_full_size_properties_of_the_other_configurations(L, torch, dec_id, M, snr, B, maxiter, modulation):
+    """Size-independent properties at the BASELINE sizes: a frame is reported converged exactly when its hard decisions satisfy
+    every parity check, return values stay in range, any sub-batch decodes to the same words, and the first / last frames of
+    the batch equal the oracle."""
+    H = relift(load_base_matrix(), M)
+    N = 32 * M
+    zero_is_converged = dec_id in (SP_DEC, TASP_DEC)           # these return 0 for an input that already is a codeword
+    with L.LdpcHip(dec_id, H, M) as dec:
+        llr = dec.awgn_llr(snr, seed=11, first_frame=0, B=B, modulation=modulation)
+        hard, iters, _ = dec.decode(llr, maxiter)
+        torch.cuda.synchronize()
+        it = iters.cpu().numpy()
+        bits = unpack_bits(hard.cpu().numpy(), N)
+        conv = it >= 0 if zero_is_converged else it > 0
+        assert 0.5 < conv.mean() <= 1.0
+        fail = syndrome_np(H, M, bits)
+        assert not fail[conv].any() and fail[~conv].all()
+        assert (it[~conv] == -maxiter).all() and it.max() <= maxiter
+        lo, hi = B // 3, B // 3 + 333
+        h2, i2, _ = dec.decode(llr[lo:hi].contiguous(), maxiter)
+        assert torch.equal(h2, hard[lo:hi]) and torch.equal(i2, iters[lo:hi])
+        o = Oracle(H, M)
+        for sl in (slice(0, 8), slice(B - 8, B)):
+            d_ref, it_ref, _ = o.decode(dec_id, llr[sl].cpu().numpy(), maxiter, 0)
+            assert np.array_equal(it[sl], it_ref) and np.array_equal(bits[sl], d_ref.astype(np.uint8))
+
+
 def test_device_noise_counting_and_simulate(L, torch):
     H = relift(load_base_matrix(), 64)
     N, R = 2048, 1024
