@@ -255,25 +255,25 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
     switch (decoder_id) {
     case LDPC_HIP_MS_DEC:
         if (M == 64) { p.body = "ms_m64_body"; p.threads = 64; p.lds = sizeof(double) * (size_t)N; }
-        else if (M >= 8 && M <= 32) {   // several frames per wavefront (+30 % over the table kernel at M = 16..32; below 8 the table kernel wins)
+        else if (M <= 32) {   // several frames per wavefront
             p.body = "ms_small_body"; p.threads = 64; p.frames_per_block = 64 / M; p.lds = sizeof(double) * (size_t)N * (size_t)(64 / M);
         }
         else if (M > 64 && M <= 128 && !(getenv("LDPC_HIP_MS_CHUNK") && atoi(getenv("LDPC_HIP_MS_CHUNK")) == 0)) {
             p.body = "ms_chunk_body"; p.threads = 64; p.lds = sizeof(double) * (size_t)N;   // one wave, two 64-lane chunks, no barriers
         }
-        else if (M >= 48 && M <= 512 && soft_lds <= 160 * 1024) { p.body = "ms_body"; p.threads = 64 * W; p.lds = soft_lds; }
+        else if (M >= 33 && M <= 512 && soft_lds <= 160 * 1024) { p.body = "ms_body"; p.threads = 64 * W; p.lds = soft_lds; }
         break;
     case LDPC_HIP_LMS_DEC:
-        if (M >= 48 && M <= 512 && soft_lds <= 160 * 1024) { p.body = "lms_body"; p.threads = 64 * W; p.lds = soft_lds; }
+        if (M >= 33 && M <= 512 && soft_lds <= 160 * 1024) { p.body = "lms_body"; p.threads = 64 * W; p.lds = soft_lds; }
         break;
     case LDPC_HIP_IMS_DEC: {   // int8 messages: MS_DBITS <= 8 and ialpha <= 16, checked per launch (the generic kernel takes the rest)
         const size_t lds = (((size_t)2 * N + 15) & ~(size_t)15) + (size_t)t.rh * 2 * LDPC_IMS_MSG_COPIES * M * 4 + 16;
-        if (M >= 48 && M <= 512 && t.max_rw <= 8 && lds <= 160 * 1024) { p.body = "ims_body"; p.threads = 64 * W; p.lds = lds; }
+        if (M >= 33 && M <= 512 && t.max_rw <= 8 && lds <= 160 * 1024) { p.body = "ims_body"; p.threads = 64 * W; p.lds = lds; }
         break;
     }
     case LDPC_HIP_SP_DEC: {
         const size_t lds = ldpc::sp_lds_bytes(t.ne, M, t.rh * M, N);
-        if (M >= 48 && lds <= 160 * 1024) { p.body = "sp_body"; p.threads = 512; p.lds = lds; }
+        if (M >= 33 && lds <= 160 * 1024) { p.body = "sp_body"; p.threads = 512; p.lds = lds; }
         break;
     }
     case LDPC_HIP_BP_DEC: {

@@ -440,8 +440,8 @@ __device__ __forceinline__ void ms_small_body(const SpecArgs &a) {
         int yo = 0;
         asm volatile("" : "+v"(yo));
         static_for<0, NH>([&](auto K) { constexpr int k = decltype(K)::value; y[k] = yrow[yo + k * M]; });
-        // ---------------- STATE1
-        static_for<0, RH>([&](auto J) {
+        // ---------------- STATE1 (one divergent region per phase: lanes of frames that have converged sit out)
+        if (!done) static_for<0, RH>([&](auto J) {
             constexpr int j = decltype(J)::value;
             u32 mt = meta[j], nb = n8;
             asm volatile("" : "+v"(mt), "+v"(nb));
@@ -453,10 +453,8 @@ __device__ __forceinline__ void ms_small_body(const SpecArgs &a) {
                 const double cv = signed_mag(aa, Wt);
                 Wt = twice(Wt);
                 double *p = reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M));
-                if (!done) {
-                    if constexpr (C::FIRST[j][s]) *p = cv;
-                    else __hip_atomic_fetch_add(p, cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                if constexpr (C::FIRST[j][s]) *p = cv;
+                else __hip_atomic_fetch_add(p, cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             });
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -474,7 +472,7 @@ __device__ __forceinline__ void ms_small_body(const SpecArgs &a) {
         asm volatile("" ::: "memory");
         // ---------------- STATE3
         u32 failw = 0;
-        static_for<0, RH>([&](auto J) {
+        if (!done) static_for<0, RH>([&](auto J) {
             constexpr int j = decltype(J)::value;
             constexpr int RW = C::RW[j];
             u32 mt = meta[j];
@@ -507,7 +505,7 @@ __device__ __forceinline__ void ms_small_body(const SpecArgs &a) {
                 nm1 = fmin(v, nm1);
             });
             failw |= sy;
-            if (!done) { m1[j] = nm1; m2[j] = nm2; meta[j] = nS | (npos << 16); }
+            m1[j] = nm1; m2[j] = nm2; meta[j] = nS | (npos << 16);
             asm volatile("" : "+v"(m1[j]), "+v"(m2[j]), "+v"(meta[j]));
             __builtin_amdgcn_sched_barrier(0);
         });

@@ -407,8 +407,9 @@ def test_both_min_sum_kernels_for_the_shipped_lifting_are_bit_exact(L, monkeypat
 def test_small_liftings_share_a_wavefront(L, torch):
     """M <= 32: floor(64/M) frames per wavefront in the code-specialised kernel; frames of one wave converge at different
     iterations and each must stop exactly where upstream stops it.  Ragged batch (last wave partly empty), M = 27 leaves 10
-    lanes idle; M < 8 stays on the table kernel."""
-    for M, frames, expect in ((32, 101, "ms_small_body"), (27, 77, "ms_small_body"), (8, 333, "ms_small_body"), (5, 200, "ms_flood_kernel")):
+    lanes idle; M = 1 puts 64 frames on a wave; 33 <= M < 64 runs one frame per wave with idle lanes."""
+    for M, frames, expect in ((32, 101, "ms_small_body"), (27, 77, "ms_small_body"), (8, 333, "ms_small_body"), (5, 200, "ms_small_body"),
+                              (1, 1000, "ms_small_body"), (40, 50, "ms_body")):
         H = relift(load_base_matrix(), M)
         llr = np.concatenate([awgn_llr(H, M, s, 90 + i, frames // 3 + 1) for i, s in enumerate((2.0, 3.5, 6.0))])[:frames]
         d_ref, it_ref, _ = Oracle(H, M).decode(MS_DEC, llr, 40, 0)
