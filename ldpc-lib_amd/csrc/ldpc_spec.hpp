@@ -1,5 +1,11 @@
-// ldpc_spec.hpp -- code-specialised decoders: flooding min-sum for lifting M = 64 (one frame == one wavefront)
-// and layered min-sum for any M <= 512 (one frame == one workgroup).
+// ldpc_spec.hpp -- code-specialised decoders for binary QC-LDPC codes on gfx950, one `body<Code>` per decoder / lifting range:
+//   ms_m64_body     flooding min-sum, M = 64, one frame == one wavefront (the flagship)
+//   ms_small_body   flooding min-sum, M <= 32, floor(64/M) frames per wavefront
+//   ms_chunk_body   flooding min-sum, 64 < M <= 128, one wavefront owning two 64-lane chunks
+//   ms_body         flooding min-sum, any other M <= 512, ceil(M/64) wavefronts per frame
+//   lms_body        layered offset min-sum            ims_body   integer (int8) min-sum
+//   sp_body / asp_body / bp_body   flooding sum-product in the likelihood-ratio / probability / log domain (8 waves per frame)
+//   tasp_body       TDMP (layered) sum-product in the probability domain
 //
 // The Tanner graph is a compile-time constant of this kernel: a `Code` type carries the base matrix (block row
 // weights, block column and shift of every circulant) as constexpr tables, so the instruction stream contains
