@@ -264,7 +264,9 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
         else if (M >= 33 && M <= 512 && soft_lds <= 160 * 1024) { p.body = "ms_body"; p.threads = 64 * W; p.lds = soft_lds; }
         break;
     case LDPC_HIP_LMS_DEC:
-        if (M >= 33 && M <= 512 && soft_lds <= 160 * 1024) { p.body = "lms_body"; p.threads = 64 * W; p.lds = soft_lds; }
+        if (M <= 32) {   // several frames per wavefront
+            p.body = "lms_small_body"; p.threads = 64; p.frames_per_block = 64 / M; p.lds = sizeof(double) * (size_t)N * (size_t)(64 / M);
+        } else if (M >= 33 && M <= 512 && soft_lds <= 160 * 1024) { p.body = "lms_body"; p.threads = 64 * W; p.lds = soft_lds; }
         break;
     case LDPC_HIP_IMS_DEC: {   // int8 messages: MS_DBITS <= 8 and ialpha <= 16, checked per launch (the generic kernel takes the rest)
         const size_t lds = (((size_t)2 * N + 15) & ~(size_t)15) + (size_t)t.rh * 2 * LDPC_IMS_MSG_COPIES * M * 4 + 16;

@@ -3,7 +3,8 @@
 //   ms_small_body   flooding min-sum, M <= 32, floor(64/M) frames per wavefront
 //   ms_chunk_body   flooding min-sum, 64 < M <= 128, one wavefront owning two 64-lane chunks
 //   ms_body         flooding min-sum, any other M <= 512, ceil(M/64) wavefronts per frame
-//   lms_body        layered offset min-sum            ims_body   integer (int8) min-sum
+//   lms_body        layered offset min-sum (lms_small_body: M <= 32, several frames per wavefront)
+//   ims_body        integer (int8) min-sum
 //   sp_body / asp_body / bp_body   flooding sum-product in the likelihood-ratio / probability / log domain (8 waves per frame)
 //   tasp_body       TDMP (layered) sum-product in the probability domain
 //
@@ -843,6 +844,135 @@ __device__ __forceinline__ void lms_body(const SpecArgs &a) {
         }
     }
     if (a.soft_out && valid) {
+        static_for<0, NH>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            a.soft_out[fr * N + k * M + n] = *reinterpret_cast<const double *>(ldsb + n8 + k * (8 * M));
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Layered offset min-sum for SMALL liftings (M <= 32): floor(64/M) frames per wavefront, lane = f*M + n, the layers of all
+// frames in lockstep (see ms_small_body).  Upstream checks the syndrome once per iteration and stops a frame there; a
+// frame that has stopped freezes (one divergent region per iteration) while the others continue.
+// ---------------------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void lms_small_body(const SpecArgs &a) {
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, F = 64 / M;
+    static_assert(M <= 32 && F >= 2, "lms_small_body: M <= 32");
+    constexpr bool POW2 = (M & (M - 1)) == 0;
+    constexpr double beta = 0.4;     // decoders.cpp:5163 (the alpha / beta arguments are dead upstream)
+    extern __shared__ double lds[];  // [F][N] soft
+    const int lane = threadIdx.x;
+    const int f = lane / M, n = lane - f * M;
+    const long long fr = (long long)blockIdx.x * F + f;
+    const bool live = f < F && fr < a.nframes;
+    char *const ldsb = reinterpret_cast<char *>(lds) + (size_t)(live ? f : 0) * N * 8;
+    const u32 n8 = (u32)n * 8u;
+    const u64 frame_lanes = (M == 32 ? 0xffffffffull : ((1ull << M) - 1ull)) << ((live ? f : 0) * M);
+
+    auto rot = [&](u32 base, auto S) -> u32 {
+        constexpr int c = decltype(S)::value;
+        if constexpr (c == 0) return base;
+        else if constexpr (POW2) return (base + 8u * (u32)c) & (u32)(8 * M - 1);
+        else { const u32 t = base + 8u * (u32)c, w = t - (u32)(8 * M); return t < w ? t : w; }
+    };
+    auto syndrome_word = [&]() -> u32 {        // check_syndrome (decoders.cpp:793-814): sign bit = this check fails
+        u32 failw = 0;
+        static_for<0, RH>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            u32 sy = 0, nb = n8;
+            asm volatile("" : "+v"(nb));
+            static_for<0, C::RW[j]>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                sy ^= *reinterpret_cast<const u32 *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M) + 4);
+            });
+            failw |= sy;
+        });
+        return failw;
+    };
+
+    if (live) {
+        static_for<0, NH>([&](auto K) {   // :5088 soft = y
+            constexpr int k = decltype(K)::value;
+            *reinterpret_cast<double *>(ldsb + n8 + k * (8 * M)) = a.llr[fr * N + k * M + n] + 0.0;
+        });
+    }
+    double m1[RH], m2[RH];
+    u32 meta[RH];
+    static_for<0, RH>([&](auto J) { constexpr int j = decltype(J)::value; m1[j] = 0.0; m2[j] = 0.0; meta[j] = 0u; });
+    asm volatile("" ::: "memory");
+
+    int res = -a.maxiter;                                  // :5424 when the loop runs dry
+    bool done = !live;
+    {
+        const u64 failing = __ballot(!done && (syndrome_word() >> 31) != 0);   // :5111-5115
+        if (!done && (failing & frame_lanes) == 0ull) { done = true; res = 1; } // :5119 at iter 0
+    }
+    for (int iter = 0; iter < a.maxiter; ++iter) {
+        if (__ballot(!done) == 0ull) break;
+        if (!done) {
+            static_for<0, RH>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                constexpr int RW = C::RW[j];
+                u32 mt = meta[j], nb = n8;
+                asm volatile("" : "+v"(mt), "+v"(nb));
+                const u32 pos = mt >> 16;
+                u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - RW);
+                double nm1 = kMaxVal, nm2 = kMaxVal;       // :5133-5134
+                u32 npos = 0, nS = 0;
+                double r[RW], tv[RW];
+                static_for<0, RW>([&](auto S) {            // :5141-5177
+                    constexpr int s = decltype(S)::value;
+                    r[s] = *reinterpret_cast<const double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M));
+                });
+                static_for<0, RW>([&](auto S) {
+                    constexpr int s = decltype(S)::value;
+                    const double aa = sel64(m1[j], m2[j], lanes_eq(pos, (u32)s));
+                    const double pc = signed_mag(aa, Wt);
+                    Wt = twice(Wt);
+                    const double tt = r[s] - pc;
+                    tv[s] = tt;
+                    nS = __builtin_amdgcn_alignbit(nS, hi32(tt), 31);
+                    double mag = fabs(tt) - beta;
+                    mag = at_least(mag, 0.0);              // :5166-5167
+                    const mask64 c1 = lanes_lt(mag, nm1);  // process_check_node :5012-5027
+                    nm2 = fmin(fmax(mag, nm1), nm2);
+                    npos = sel32(npos, (u32)s, c1);
+                    nm1 = fmin(mag, nm1);
+                });
+                u32 Wn = (nS ^ (0u - (__popc(nS) & 1u))) << (32 - RW);
+                static_for<0, RW>([&](auto S) {            // :5182-5206
+                    constexpr int s = decltype(S)::value;
+                    const double aa = sel64(nm1, nm2, lanes_eq(npos, (u32)s));
+                    const double cv = signed_mag(aa, Wn);
+                    Wn = twice(Wn);
+                    *reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M)) = tv[s] + cv;
+                });
+                m1[j] = nm1; m2[j] = nm2; meta[j] = nS | (npos << 16);
+                asm volatile("" ::: "memory");             // the next layer reads what this one wrote (LDS runs a wave's accesses in order)
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        asm volatile("" ::: "memory");
+        const u64 failing = __ballot(!done && (syndrome_word() >> 31) != 0);   // :5281-5284
+        if (!done && (failing & frame_lanes) == 0ull) { done = true; res = iter + 1; }   // :5287
+    }
+
+    if (!live) return;
+    if (n == 0 && a.iters) a.iters[fr] = res;
+    if (a.hard) {
+        constexpr int HW = (N + 31) / 32;
+        for (int w = n; w < HW; w += M) {
+            u32 bits = 0;
+            for (int b = 0; b < 32; ++b) {
+                const int v = 32 * w + b;
+                if (v < N) bits |= (*reinterpret_cast<const u32 *>(ldsb + (size_t)v * 8 + 4) >> 31) << b;
+            }
+            a.hard[fr * HW + w] = bits;
+        }
+    }
+    if (a.soft_out) {
         static_for<0, NH>([&](auto K) {
             constexpr int k = decltype(K)::value;
             a.soft_out[fr * N + k * M + n] = *reinterpret_cast<const double *>(ldsb + n8 + k * (8 * M));

@@ -405,23 +405,23 @@ def test_both_min_sum_kernels_for_the_shipped_lifting_are_bit_exact(L, monkeypat
 
 
 def test_small_liftings_share_a_wavefront(L, torch):
-    """M <= 32: floor(64/M) frames per wavefront in the code-specialised kernel; frames of one wave converge at different
-    iterations and each must stop exactly where upstream stops it.  Ragged batch (last wave partly empty), M = 27 leaves 10
-    lanes idle; M = 1 puts 64 frames on a wave; 33 <= M < 64 runs one frame per wave with idle lanes."""
-    for M, frames, expect in ((32, 101, "ms_small_body"), (27, 77, "ms_small_body"), (8, 333, "ms_small_body"), (5, 200, "ms_small_body"),
-                              (1, 1000, "ms_small_body"), (40, 50, "ms_body")):
-        H = relift(load_base_matrix(), M)
-        llr = np.concatenate([awgn_llr(H, M, s, 90 + i, frames // 3 + 1) for i, s in enumerate((2.0, 3.5, 6.0))])[:frames]
-        d_ref, it_ref, _ = Oracle(H, M).decode(MS_DEC, llr, 40, 0)
-        s_ref, _, _ = Oracle(H, M).decode(MS_DEC, llr, 40, 1)
-        with L.LdpcHip(MS_DEC, H, M) as dec:
-            assert expect in dec.kernel_name, dec.kernel_name
-            hard, iters, soft = dec.decode(torch.from_numpy(llr).cuda(), 40, want_soft=True)
-            torch.cuda.synchronize()
-            assert np.array_equal(iters.cpu().numpy(), it_ref)
-            assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
-            assert np.array_equal(soft.cpu().numpy(), s_ref)
-        assert len(set(it_ref.tolist())) > 3      # the frames of a wave really do stop at different iterations
+    """M <= 32: floor(64/M) frames per wavefront in the code-specialised min-sum and layered min-sum kernels; frames of one wave
+    converge at different iterations and each must stop exactly where upstream stops it.  Ragged batch (last wave partly
+    empty), M = 27 leaves 10 lanes idle; M = 1 puts 64 frames on a wave; 33 <= M < 64 runs one frame per wave with idle lanes."""
+    for dec_id, small, one in ((MS_DEC, "ms_small_body", "ms_body"), (LMS_DEC, "lms_small_body", "lms_body")):
+        for M, frames, expect in ((32, 101, small), (27, 77, small), (8, 333, small), (5, 200, small), (1, 1000, small), (40, 50, one)):
+            H = relift(load_base_matrix(), M)
+            llr = np.concatenate([awgn_llr(H, M, s, 90 + i, frames // 3 + 1) for i, s in enumerate((2.0, 3.5, 6.0))])[:frames]
+            d_ref, it_ref, _ = Oracle(H, M).decode(dec_id, llr, 40, 0)
+            s_ref, _, _ = Oracle(H, M).decode(dec_id, llr, 40, 1)
+            with L.LdpcHip(dec_id, H, M) as dec:
+                assert expect in dec.kernel_name, dec.kernel_name
+                hard, iters, soft = dec.decode(torch.from_numpy(llr).cuda(), 40, want_soft=True)
+                torch.cuda.synchronize()
+                assert np.array_equal(iters.cpu().numpy(), it_ref), (dec_id, M)
+                assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref)), (dec_id, M)
+                assert np.array_equal(soft.cpu().numpy(), s_ref), (dec_id, M)
+            assert len(set(it_ref.tolist())) > 3      # the frames of a wave really do stop at different iterations
 
 
 def test_flagship_code_uses_the_ahead_of_time_instance(L):
