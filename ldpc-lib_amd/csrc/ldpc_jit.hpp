@@ -8,11 +8,13 @@
 #pragma once
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -126,6 +128,28 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
     const std::string src = "#include \"ldpc_spec.hpp\"\nnamespace {\n" + code +
                             "}\nextern \"C\" __global__ void __launch_bounds__(" + std::to_string(threads) + (eight_waves ? ", 4" : (std::string(body) == "tasp_body" || std::string(body) == "ms_chunk_body") ? ", 1" : ", 2") + ") spec_jit(const ldpc_spec::SpecArgs a) {\n"
                             "    ldpc_spec::" + body + "<Code>(a);\n}\n";
+    // Optional on-disk cache of compiled code objects (LDPC_HIP_CACHE_DIR; off by default): the file name is a hash of
+    // everything the object depends on -- the generated source, this header's text and the target.
+    std::string cache_file;
+    if (const char *dir = getenv("LDPC_HIP_CACHE_DIR")) {
+        unsigned long long h = 1469598103934665603ull;   // FNV-1a 64
+        auto mix = [&](const std::string &t) { for (unsigned char ch : t) { h ^= ch; h *= 1099511628211ull; } };
+        mix(src); mix(hdr); mix("gfx950 -O3 -ffp-contract=off");
+        char name[64];
+        snprintf(name, sizeof name, "/ldpc_spec_%016llx.hsaco", h);
+        cache_file = std::string(dir) + name;
+        std::ifstream cf(cache_file, std::ios::binary);
+        if (cf) {
+            std::vector<char> bin((std::istreambuf_iterator<char>(cf)), std::istreambuf_iterator<char>());
+            Kernel k;
+            if (!bin.empty() && hipSetDevice(device) == hipSuccess && hipModuleLoadData(&k.mod, bin.data()) == hipSuccess &&
+                hipModuleGetFunction(&k.fn, k.mod, "spec_jit") == hipSuccess) {
+                auto ins = cache.emplace(key, k);
+                return &ins.first->second;
+            }
+            (void)hipGetLastError();   // unreadable / stale file: compile again below and overwrite it
+        }
+    }
     hiprtcProgram prog = nullptr;
     const char *hdr_src[] = {hdr.c_str()};
     const char *hdr_name[] = {"ldpc_spec.hpp"};
@@ -152,6 +176,13 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
         hipModuleGetFunction(&k.fn, k.mod, "spec_jit") != hipSuccess) {
         err = std::string("loading the JIT code object failed: ") + hipGetErrorString(hipGetLastError());
         return nullptr;
+    }
+    if (!cache_file.empty()) {   // best effort, atomically: a concurrent process either sees the whole file or none
+        const std::string tmp = cache_file + ".tmp" + std::to_string((long long)getpid());
+        std::ofstream of(tmp, std::ios::binary);
+        if (of && of.write(bin.data(), (std::streamsize)bin.size()) && (of.close(), true)) {
+            if (rename(tmp.c_str(), cache_file.c_str()) != 0) (void)remove(tmp.c_str());
+        }
     }
     auto ins = cache.emplace(key, k);
     return &ins.first->second;

@@ -760,3 +760,28 @@ def test_non_zero_codewords_decode_like_the_zero_codeword(L, torch, M):
             assert wrong.sum() <= 2, dec_id
             assert np.array_equal(wrong, (d0[conv] != 0).any(axis=1)) or wrong.sum() <= 1, dec_id   # ... and the zero-codeword run agrees on which
             assert np.abs(it0[conv] - it1[conv]).max() <= 3, dec_id
+
+
+def test_hiprtc_code_objects_can_be_cached_on_disk(L, tmp_path, monkeypatch):
+    """LDPC_HIP_CACHE_DIR: the first open of an unseen code compiles and leaves one .hsaco per (decoder body, code); a fresh
+    process picks it up instead of compiling (seconds -> milliseconds) and decodes the same bits."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import sys, time, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch, ldpc_lib_amd as L\n"
+        "from ldpc_testlib import MS_DEC, awgn_llr, load_base_matrix, relift\n"
+        "H = relift(load_base_matrix(), 64).copy(); H[H > 0] = (H[H > 0] * 5 + 1) %% 64\n"
+        "t0 = time.perf_counter(); dec = L.LdpcHip(MS_DEC, H, 64); t = time.perf_counter() - t0\n"
+        "d, it, _ = dec.decode_host(awgn_llr(H, 64, 2.0, 3, 16), 50)\n"
+        "print(dec.kernel_name, '|', t, '|', it.tolist(), '|', int(d.sum()))\n") % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, LDPC_HIP_CACHE_DIR=str(tmp_path))
+    out1 = subprocess.check_output([sys.executable, "-c", prog], env=env, text=True).strip().split("\n")[-1].split("|")
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    assert "hiprtc" in out1[0] and len(files) == 1
+    out2 = subprocess.check_output([sys.executable, "-c", prog], env=env, text=True).strip().split("\n")[-1].split("|")
+    assert out2[2:] == out1[2:] and "hiprtc" in out2[0]
+    assert float(out2[1]) < 0.5 * float(out1[1]) or float(out2[1]) < 0.3      # no compilation the second time
+    assert [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")] == files
