@@ -270,7 +270,11 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
         break;
     case LDPC_HIP_IMS_DEC: {   // int8 messages: MS_DBITS <= 8 and ialpha <= 16, checked per launch (the generic kernel takes the rest)
         const size_t lds = (((size_t)2 * N + 15) & ~(size_t)15) + (size_t)t.rh * 2 * LDPC_IMS_MSG_COPIES * M * 4 + 16;
-        if (M >= 33 && M <= 512 && t.max_rw <= 8 && lds <= 160 * 1024) { p.body = "ims_body"; p.threads = 64 * W; p.lds = lds; }
+        if (M <= 32 && t.max_rw <= 8) {   // several frames per wavefront
+            const size_t Fr = 64 / M;
+            p.body = "ims_small_body"; p.threads = 64; p.frames_per_block = (int)Fr;
+            p.lds = ((Fr * 2 * N + 15) & ~(size_t)15) + Fr * (size_t)t.rh * 2 * LDPC_IMS_MSG_COPIES * M * 4 + 16;
+        } else if (M >= 33 && M <= 512 && t.max_rw <= 8 && lds <= 160 * 1024) { p.body = "ims_body"; p.threads = 64 * W; p.lds = lds; }
         break;
     }
     case LDPC_HIP_SP_DEC: {

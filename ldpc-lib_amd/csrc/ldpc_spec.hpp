@@ -4,7 +4,7 @@
 //   ms_chunk_body   flooding min-sum, 64 < M <= 128, one wavefront owning two 64-lane chunks
 //   ms_body         flooding min-sum, any other M <= 512, ceil(M/64) wavefronts per frame
 //   lms_body        layered offset min-sum (lms_small_body: M <= 32, several frames per wavefront)
-//   ims_body        integer (int8) min-sum
+//   ims_body        integer (int8) min-sum (ims_small_body: M <= 32, several frames per wavefront)
 //   sp_body / asp_body / bp_body   flooding sum-product in the likelihood-ratio / probability / log domain (8 waves per frame)
 //   tasp_body       TDMP (layered) sum-product in the probability domain
 //
@@ -1645,21 +1645,30 @@ struct ColView {   // column view of the code, compile time
     }
 };
 
-template <class C>
-__device__ __forceinline__ void ims_body(const SpecArgs &a) {
+// SMALL: M <= 32, floor(64/M) frames per wavefront (lane = f*M + n); a frame that has converged freezes while the others of
+// its wave go on (see ms_small_body).  Otherwise one frame per workgroup of ceil(M/64) waves.
+template <class C, bool SMALL>
+__device__ __forceinline__ void ims_body_t(const SpecArgs &a) {
     static_assert(C::WMAX <= 8, "ims_body: at most 8 circulants per block row (message bytes in 2 dwords)");
     constexpr ColView<C> V{};
     constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, W = (M + 63) / 64;
+    static_assert(!SMALL || (M <= 32 && W == 1), "ims_small_body: M <= 32");
     extern __shared__ double lds[];
-    char *const softb = reinterpret_cast<char *>(lds);                     // soft2[k][2M] int8
     // MC copies of the message array: 2 = rotation by immediate offset (fewer VALU), 1 = half the LDS (more frames per CU)
     constexpr int MC = LDPC_IMS_MSG_COPIES;
-    char *const msgb = softb + ((2 * N + 15) & ~15);                       // msg[j][2][MC*M] dwords
-    int *const flag = reinterpret_cast<int *>(msgb + (size_t)RH * 2 * MC * M * 4);
-    const int n = threadIdx.x;
-    const bool valid = (M % 64 == 0) || n < M;
+    constexpr int F = SMALL ? 64 / M : 1;                                   // frames per workgroup
+    constexpr size_t kSoftBytes = (size_t)2 * N, kMsgBytes = (size_t)RH * 2 * MC * M * 4, kMsgBase = (F * kSoftBytes + 15) & ~(size_t)15;
+    char *const lds0 = reinterpret_cast<char *>(lds);
+    int *const flag = reinterpret_cast<int *>(lds0 + kMsgBase + F * kMsgBytes);
+    const int f = SMALL ? (int)threadIdx.x / M : 0;
+    const int n = SMALL ? (int)threadIdx.x - f * M : (int)threadIdx.x;
+    const long long fr = SMALL ? (long long)blockIdx.x * F + f : (long long)blockIdx.x;
+    const bool valid = SMALL ? (f < F && fr < a.nframes) : ((M % 64 == 0) || n < M);
     const int nv = valid ? n : 0;
-    const long long fr = blockIdx.x;
+    const long long frv = valid ? fr : 0;
+    char *const softb = lds0 + (size_t)(valid ? f : 0) * kSoftBytes;        // this frame's soft2[k][2M] int8
+    char *const msgb = lds0 + kMsgBase + (size_t)(valid ? f : 0) * kMsgBytes;   // this frame's msg[j][2][MC*M] dwords
+    const u64 frame_lanes = SMALL ? ((M >= 32 ? 0xffffffffull : ((1ull << (M & 31)) - 1ull)) << ((valid ? f : 0) * M)) : ~0ull;
     const int md = a.ims_max_data, nmd = -a.ims_max_data;
     // Lanes talk to each other through LDS.  Several waves: a workgroup barrier.  One wave: LDS executes a wave's accesses in
     // program order, but the COMPILER only sees one thread and would move a load of [base + lane + c] above the store to
@@ -1678,8 +1687,8 @@ __device__ __forceinline__ void ims_body(const SpecArgs &a) {
 
     int iy[NH];                                                             // :5472-5500 energy-normalised quantiser
     {
-        const double coef = a.ims_coef[fr];
-        const double *yrow = a.llr + fr * N + nv;
+        const double coef = a.ims_coef[frv];
+        const double *yrow = a.llr + frv * N + nv;
         static_for<0, NH>([&](auto K) {
             constexpr int k = decltype(K)::value;
             double val = yrow[k * M];
@@ -1707,7 +1716,10 @@ __device__ __forceinline__ void ims_body(const SpecArgs &a) {
     phase_fence();
 
     int res = -a.maxiter;
+    bool done = SMALL ? !valid : false;
     for (int iter = 0; iter < a.maxiter; ++iter) {
+        u32 failw = 0;
+        if (SMALL ? !done : true) {      // one divergent region per iteration for the frames of a wave that are still running
         // ---------------- STATE1 + STATE2 on the variable lane (:5540-5604)
         // Software pipeline: the message bytes of column group g+1 are requested before group g is summed, and soft2 is
         // written only after every column is done (the compiler cannot tell msg2 from soft2, so a store in between would
@@ -1759,7 +1771,6 @@ __device__ __forceinline__ void ims_body(const SpecArgs &a) {
         }
         phase_fence();
         // ---------------- STATE3 on the check lane (:5610-5678) + the messages of the next STATE1
-        u32 failw = 0;
         int rb[2][8];                                                         // soft values of block row j / j+1 (same pipeline)
         auto request_row = [&](auto JI) {
             constexpr int j = decltype(JI)::value;
@@ -1818,15 +1829,23 @@ __device__ __forceinline__ void ims_body(const SpecArgs &a) {
                 }
             });
         }
+        }
         if constexpr (W == 1) phase_fence();                                  // (the vote's barriers do it for several waves)
-        if (!vote(valid && (failw >> 31) != 0)) { res = iter + 1; break; }    // :5684-5689
+        if constexpr (SMALL) {
+            const u64 failing = __ballot(!done && (failw >> 31) != 0);        // per check, frames still running
+            if (!done && (failing & frame_lanes) == 0ull) { done = true; res = iter + 1; }   // :5684-5689, per frame
+            if (__ballot(!done) == 0ull) break;
+        } else {
+            if (!vote(valid && (failw >> 31) != 0)) { res = iter + 1; break; }    // :5684-5689
+        }
     }
 
-    if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
+    if constexpr (SMALL) { if (!valid) return; }
+    if ((SMALL ? n == 0 : threadIdx.x == 0) && a.iters) a.iters[fr] = res;
     phase_fence();
     if (a.hard) {
         constexpr int HW = (N + 31) / 32;
-        for (int w = threadIdx.x; w < HW; w += W * 64) {
+        for (int w = SMALL ? n : (int)threadIdx.x; w < HW; w += SMALL ? M : W * 64) {
             u32 bits = 0;
             for (int b = 0; b < 32; ++b) {
                 const int v = 32 * w + b;
@@ -1842,5 +1861,8 @@ __device__ __forceinline__ void ims_body(const SpecArgs &a) {
         });
     }
 }
+
+template <class C> __device__ __forceinline__ void ims_body(const SpecArgs &a) { ims_body_t<C, false>(a); }
+template <class C> __device__ __forceinline__ void ims_small_body(const SpecArgs &a) { ims_body_t<C, true>(a); }
 
 }  // namespace ldpc_spec

@@ -405,10 +405,10 @@ def test_both_min_sum_kernels_for_the_shipped_lifting_are_bit_exact(L, monkeypat
 
 
 def test_small_liftings_share_a_wavefront(L, torch):
-    """M <= 32: floor(64/M) frames per wavefront in the code-specialised min-sum and layered min-sum kernels; frames of one wave
+    """M <= 32: floor(64/M) frames per wavefront in the code-specialised min-sum, layered and integer min-sum kernels; frames of one wave
     converge at different iterations and each must stop exactly where upstream stops it.  Ragged batch (last wave partly
     empty), M = 27 leaves 10 lanes idle; M = 1 puts 64 frames on a wave; 33 <= M < 64 runs one frame per wave with idle lanes."""
-    for dec_id, small, one in ((MS_DEC, "ms_small_body", "ms_body"), (LMS_DEC, "lms_small_body", "lms_body")):
+    for dec_id, small, one in ((MS_DEC, "ms_small_body", "ms_body"), (LMS_DEC, "lms_small_body", "lms_body"), (IMS_DEC, "ims_small_body", "ims_body")):
         for M, frames, expect in ((32, 101, small), (27, 77, small), (8, 333, small), (5, 200, small), (1, 1000, small), (40, 50, one)):
             H = relift(load_base_matrix(), M)
             llr = np.concatenate([awgn_llr(H, M, s, 90 + i, frames // 3 + 1) for i, s in enumerate((2.0, 3.5, 6.0))])[:frames]
