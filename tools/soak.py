@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Randomised soak: random protographs x liftings x decoders on the GPU against the CPU oracle (bit-exact decoders only by
+default).  Not part of the test-suite (every case compiles its own hiprtc instance); run by hand:
+    python tools/soak.py [cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ldpc_lib_amd as L  # noqa: E402
+from ldpc_testlib import IMS_DEC, LMS_DEC, MS_DEC, Oracle, awgn_llr, pack_bits, random_qc_code  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time()
+bad = 0
+for case in range(cases):
+    rh = int(rng.randint(2, 13))
+    nh = rh + int(rng.randint(2, 14))
+    M = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 21, 27, 32, 33, 40, 47, 48, 63, 64, 65, 67, 96, 100, 126, 128, 129, 160, 200, 256]))
+    weights = tuple(int(x) for x in rng.randint(2, min(rh, 6) + 1, size=4))
+    H = random_qc_code(rng, rh, nh, M, weights)
+    if (H >= 0).sum(axis=1).max() > 8:
+        continue
+    frames = 24 if M * nh > 2000 else 70
+    llr = np.concatenate([awgn_llr(H, M, s, 500 + case, frames // 2) for s in (2.0, 5.0)])
+    llr[0, :3] = [0.0, -0.0, 40000.0]
+    for dec_id in (MS_DEC, LMS_DEC, IMS_DEC):
+        o = Oracle(H, M)
+        d_ref, it_ref, _ = o.decode(dec_id, llr, 30, 0)
+        s_ref, _, _ = Oracle(H, M).decode(dec_id, llr, 30, 1)
+        with L.LdpcHip(dec_id, H, M) as dec:
+            hard, iters, soft = dec.decode(torch.from_numpy(llr).cuda(), 30, want_soft=True)
+            torch.cuda.synchronize()
+            ok = (np.array_equal(iters.cpu().numpy(), it_ref) and np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
+                  and np.array_equal(soft.cpu().numpy(), s_ref))
+            print(f"case {case:3d} rh={rh:2d} nh={nh:2d} M={M:3d} dec={dec_id} {dec.kernel_name:40s} {'ok' if ok else 'MISMATCH'}  ({time.time() - t0:.0f}s)", flush=True)
+            bad += not ok
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
