@@ -31,7 +31,9 @@ def build_library(force=False, verbose=False):
     -ffp-contract=off is part of the numerics contract: `y + s*alpha` must stay two roundings (decoders.cpp:4682)."""
     src_dir = os.path.join(_PKG_DIR, "csrc")
     srcs = [os.path.join(src_dir, "ldpc_hip.hip")]
-    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir)] + [os.path.join(_ROOT, "include", "ldpc_hip.h")]
+    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if os.path.isfile(os.path.join(src_dir, f))]
+    deps += [os.path.join(_ROOT, "include", "ldpc_hip.h"), os.path.join(_ROOT, "include", "ldpc", "interleaver.h"),
+             os.path.join(_ROOT, "include", "ldpc", "encoder.h")]
     out = library_path()
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
