@@ -11,7 +11,7 @@
 //   D (check lanes)     syndrome = xor over the row's edges of (soft < 1.0)                           (:2129-2149)
 // One frame per 256-thread workgroup.  LDS holds the per-edge messages ZZ[ne][M] (fp64), the check products
 // s[R] and one hard-decision byte per variable; yd and soft of a thread's <= 8 variables stay in VGPRs.
-// exp() is ocml's (<= 1 ulp) where the CPU reference uses glibc's, so soft values agree to rounding, not bitwise.
+// exp() is evaluated with glibc's algorithm (ldpc_spec::exp_glibc), so soft values equal the CPU reference's bitwise.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(kSpThreads) sp_flood_kernel(const DecArgs a) {
         yd[q] = 1.0; sf[q] = 1.0;
         if (v < N) {
             const double yl = sp_maxd(sp_mind(a.llr[fr * N + v], 20.0), -20.0);  // :1949 INPUT_LIMIT
-            yd[q] = sf[q] = exp(yl);
+            yd[q] = sf[q] = ldpc_spec::exp_glibc(yl);   // the reference's exp(), bit for bit (ldpc_spec.hpp)
             hb[v] = sf[q] < 1.0;
         }
     }

@@ -312,3 +312,38 @@ def test_encoder_returns_the_unique_systematic_codeword():
     bad[15, 15] = 0
     with pytest.raises(LdpcHipError):
         encode(bad, 8, np.ones(16 * 8, dtype=np.uint8))
+
+
+def test_device_exp_algorithm_equals_libm_exp_bit_for_bit(tmp_path):
+    """ldpc_spec::exp_glibc (the one transcendental of the SP / ASP / TDMP decoders) is glibc's exp() algorithm with a table
+    computed by tools/gen_exp_table.py.  A C transcription of exactly that code -- same constants, same table, same fma
+    placement -- must return libm's exp() bit for bit on this host (x86-64 with FMA: glibc's run-time selected FMA build), over
+    the decoders' whole input range; and the header's table must be the generator's."""
+    import subprocess
+    flags = open("/proc/cpuinfo").read()
+    if " fma" not in flags:
+        pytest.skip("host without FMA: glibc selects its non-FMA exp build there")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_exp_table
+    tab = gen_exp_table.table()
+    hdr = open(os.path.join(ROOT, "ldpc-lib_amd", "csrc", "ldpc_spec.hpp")).read()
+    body = hdr[hdr.index("kExpTab[256] = {") + len("kExpTab[256] = {"):]
+    body = body[:body.index("};")]
+    assert [int(x.strip().rstrip("ull"), 16) for x in body.replace("\n", " ").split(",") if x.strip()] == tab
+    fn = hdr[hdr.index("__device__ __forceinline__ double exp_glibc(double x) {"):]
+    fn = fn[:fn.index("\n}\n") + 3]
+    c_fn = (fn.replace("__device__ __forceinline__ ", "static ").replace("__fma_rn", "fma")
+              .replace("(unsigned long long)__double_as_longlong(kd)", "asu(kd)")
+              .replace("__longlong_as_double((long long)kExpTab[idx])", "asd(kExpTab[idx])")
+              .replace("__longlong_as_double((long long)sbits)", "asd(sbits)"))
+    src = ("#include <math.h>\n#include <stdint.h>\n#include <stdio.h>\n#include <string.h>\n"
+           "static unsigned long long asu(double x){unsigned long long u;memcpy(&u,&x,8);return u;}\n"
+           "static double asd(unsigned long long u){double x;memcpy(&x,&u,8);return x;}\n"
+           "static const unsigned long long kExpTab[256] = {" + ",".join("0x%xull" % v for v in tab) + "};\n" + c_fn +
+           "int main(){unsigned long long s=88172645463325252ull;long bad=0,n=4000000;\n"
+           " for(long i=0;i<n;i++){s^=s<<13;s^=s>>7;s^=s<<17;double x=((double)(s>>11)/9007199254740992.0)*42.0-21.0;\n"
+           "  if(i<2000) x=(i-1000)*1e-19; if(asu(exp_glibc(x))!=asu(exp(x))) bad++;}\n"
+           " printf(\"%ld\\n\",bad);return bad!=0;}\n")
+    (tmp_path / "e.c").write_text(src)
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", str(tmp_path / "e.c"), "-o", str(tmp_path / "e"), "-lm"])
+    assert subprocess.check_output([str(tmp_path / "e")], text=True).strip() == "0"

@@ -20,7 +20,7 @@ rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 FAMILY = (SP_DEC, ASP_DEC, TASP_DEC, BP_DEC) if "--sp" in sys.argv else (MS_DEC, LMS_DEC, IMS_DEC)
 if "--only" in sys.argv:
     FAMILY = (int(sys.argv[sys.argv.index("--only") + 1]),)   # --sp: sum-product family, soft values to tolerance
-TOL = {SP_DEC: (1e-6, 0.0), ASP_DEC: (1e-4, 0.0), TASP_DEC: (1e-4, 0.0), BP_DEC: (1e-5, 1e-7)}
+TOL = {BP_DEC: (1e-5, 1e-7)}   # SP / ASP / TDMP: exp() is glibc's algorithm on the device -> soft values bit for bit
 t0 = time.time()
 bad = 0
 for case in range(cases):
