@@ -82,6 +82,9 @@ const char *ldpc_hip_last_launch(const ldpc_hip_ctx *ctx);
  *   d_hard  [B][ceil(N/32)] uint32 out: bit (v%32) of word v/32 = hard decision of variable v
  *           (upstream decword[v] = soft<0, resp. soft<1.0 for SP), or NULL
  *   d_iters [B] int32 out: upstream return value, or NULL
+ * Numerics: outputs equal upstream's on the same inputs bit for bit -- hard decisions, return values and soft values -- for
+ * MS, LMS, IMS, SP, ASP and TASP (fp64 in upstream's operation order, no FMA contraction; exp() by glibc's algorithm);
+ * BP: hard decisions and return values identical, soft values within rtol 1e-5 / atol 1e-7 (its exp / log are the device's).
  *   d_soft  [B][N] float64 out, or NULL: the a-posteriori values upstream writes to decword[] when decision==1
  *           (MS/LMS: LLR; SP: likelihood ratio = what upstream leaves in soft[])
  */
