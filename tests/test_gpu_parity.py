@@ -440,6 +440,7 @@ def _compat_lib(L):
 
 @pytest.mark.parametrize("dec_id,M,snr,maxit,n_fe,n_exp,ref,mod,punct,seed", [
     (MS_DEC, 64, 2.0, 50, 10**9, 700, 1.0, 0, 0, 1),        # runs the whole budget: 701 frames (bp_simulation.cpp:591 `<=`)
+    (MS_DEC, 64, 2.0, 50, 10**9, 4000, 1.0, 0, 0, 1),       # BASELINE.md section 2, cfg2, the headline configuration: 170 errored frames in 4001
     (MS_DEC, 64, 1.2, 50, 10**9, 5000, 0.02, 0, 0, 1),      # stops early on the FER rule (:820): generator roll-back
     (MS_DEC, 64, 1.4, 50, 7, 5000, 1.0, 0, 0, 3),           # stops on n_frame_errors
     (LMS_DEC, 126, 1.7, 50, 10**9, 150, 1.0, 0, 0, 1),
@@ -472,6 +473,61 @@ def test_exact_replay_harness_equals_the_sequential_harness(L, dec_id, M, snr, m
         assert (res.nde, res.experiment) == (50, 821)       # FER 0.061 measured by the survey with the upstream binary
     if (dec_id, M, n_exp, seed) == (MS_DEC, 1, 2000, 1):
         assert res.nde == 112 and res.experiment == 2001   # the FER 0.056 the survey measured with the compiled upstream binary
+    if (dec_id, M, n_exp, seed, snr) == (MS_DEC, 64, 4000, 1, 2.0):
+        assert (res.nde, res.experiment) == (170, 4001)     # FER 0.0425 of BASELINE.md section 2 (cfg2), upstream binary, seed 1
+
+
+DROPIN_CASES = [
+    # dec, M, snr, maxit, n_fe, n_exp, ref, mod, ptype, pblock, pinter, punct, seed
+    (MS_DEC, 64, 2.0, 50, 10**9, 4000, 1.0, 0, 0, 128, 1, 0, 1),     # cfg2 headline: 170 / 4001
+    (MS_DEC, 64, 1.2, 50, 10**9, 5000, 0.02, 0, 0, 128, 1, 0, 1),    # early stop on the FER rule: generator roll-back on upstream's own object
+    (TASP_DEC, 126, 1.7, 15, 50, 10**8, 1.0, 0, 0, 128, 1, 0, 1),    # the shipped `search` scenario: 50 / 821
+    (LMS_DEC, 64, 1.6, 50, 10**9, 300, 1.0, 1, 3, 64, 1, 2, 9),      # QAM4 + block interleaver + two punctured blocks
+]
+
+
+@pytest.mark.parametrize("case", DROPIN_CASES)
+def test_upstream_bp_simulation_symbol_runs_on_the_gpu(L, case):
+    """oracle/_ref/dropin_driver = csrc/compat/bp_simulation_dropin.cpp + decoders_compat.cpp compiled against UPSTREAM'S OWN
+    bp_simulation.h / data_structures.h / commons_portable.h / decoders.h (oracle/Makefile `ref`, built where the upstream tree
+    is mounted) and linked into a program that calls the exact symbol main_simulation.cpp:500 binds.  Its BER / FER doubles and
+    the generator state it leaves in upstream's `generator` object must equal the sequential harness restatement's."""
+    import ctypes as C
+    import subprocess
+    from ldpc_testlib import SimResult, c_int_p, oracle_lib
+    dec_id, M, snr, maxit, n_fe, n_exp, ref, mod, ptype, pblock, pinter, punct, seed = case
+    exe = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "oracle", "_ref", "dropin_driver")
+    assert os.path.exists(exe), "oracle/_ref/dropin_driver missing: run `make -C oracle ref` where /root/reference is mounted"
+    H = np.ascontiguousarray(relift(load_base_matrix(), M), dtype=np.int32)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        hp = os.path.join(td, "H.txt")
+        np.savetxt(hp, H, fmt="%d")
+        out = subprocess.run([exe, hp, "16", "32", str(M), str(maxit), str(n_fe), str(n_exp), repr(snr), repr(ref), str(dec_id),
+                              str(mod), str(ptype), str(pblock), str(pinter), str(punct), str(seed)],
+                             check=True, capture_output=True, text=True, timeout=900).stdout
+    got = dict(line.split() for line in out.strip().splitlines() if line[:3] in ("BER", "FER", "RNG", "MS_"))
+    olib = oracle_lib()
+    res = SimResult()
+    if ptype == 0:
+        assert olib.orc_bp_simulation(16, 32, H.ctypes.data_as(c_int_p), M, maxit, n_fe, n_exp, snr, ref, dec_id, mod, punct, seed,
+                                      C.byref(res), None) == 0
+    else:
+        from ldpc_lib_amd.binding import build_interleaver
+        direct, inv = build_interleaver(H, M, ptype, 1, pblock, pinter)
+        inv = np.ascontiguousarray(inv, dtype=np.int32)
+        olib.orc_bp_simulation_perm.argtypes = [C.c_int, C.c_int, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                                C.c_int, C.c_uint, c_int_p, C.POINTER(SimResult), c_int_p]
+        assert olib.orc_bp_simulation_perm(16, 32, H.ctypes.data_as(c_int_p), M, maxit, n_fe, n_exp, snr, ref, dec_id, mod, punct, seed,
+                                           inv.ctypes.data_as(c_int_p), C.byref(res), None) == 0
+    assert float.fromhex(got["BER"]) == res.ber and float.fromhex(got["FER"]) == res.fer
+    assert int(got["RNG"]) == res.rng_next
+    if case is DROPIN_CASES[0]:
+        assert (res.nde, res.experiment) == (170, 4001) and float.fromhex(got["FER"]) == 170 / 4001
+    if dec_id == TASP_DEC:
+        assert (res.nde, res.experiment) == (50, 821)
+    # the decoders.h call made through upstream's DEC_STATE layout: same frame through the C-ABI
+    assert int(got["MS_ITERS"]) != 0 and 0 <= int(got["MS_ONES"]) <= 32 * M
 
 
 @pytest.mark.parametrize("name", ["ms_m64_1p2", "lms_m64_0p8", "sp_m64_2p0", "ms_m126_1p7", "ms_m1_4p0", "ims_m64_2p0", "tasp_m126_1p7",

@@ -83,3 +83,21 @@ def test_bp_outputs_survive_one_ulp_perturbations(tmp_path):
             i2[f] = pl.orc_bp(h, y.ctypes.data, d2[f].ctypes.data, 50, 0)
         assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
         assert snr > 1.0 or (i1 < 0).sum() >= frames // 3   # the low point holds many failing frames
+
+
+@pytest.mark.parametrize("dec_id,M,maxit,n_exp,snr,nde,experiment", [
+    (3, 64, 50, 4000, 2.0, 170, 4001),     # cfg2, the headline configuration (FER 0.0425)
+    (3, 1, 20, 2000, 4.0, 112, 2001),      # cfg1
+    (1, 64, 50, 2000, 2.0, 13, 2001),      # cfg3 sum-product
+])
+def test_harness_restatement_reproduces_the_surveys_upstream_counts(dec_id, M, maxit, n_exp, snr, nde, experiment):
+    """errored-frame counts the survey measured with the upstream binary (seed 1, all-zero codeword,
+    BPSK).  The sequential harness restatement must return exactly these; the GPU harness is then compared with it."""
+    import ctypes as C
+    from ldpc_testlib import SimResult, c_int_p
+    H = np.ascontiguousarray(relift(load_base_matrix(), M), dtype=np.int32)
+    res = SimResult()
+    assert oracle_lib().orc_bp_simulation(16, 32, H.ctypes.data_as(c_int_p), M, maxit, 10**9, n_exp, snr, 1.0, dec_id, 0, 0, 1,
+                                          C.byref(res), None) == 0
+    assert (res.nde, res.experiment) == (nde, experiment)
+    assert res.fer == nde / experiment
