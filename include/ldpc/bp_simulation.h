@@ -8,6 +8,11 @@
  * Result, counters and generator state are identical to upstream's for q_mod == 2, modulation SKIP/QAM4,
  * permutation_type 0 (the only mode the shipped configurations use, files/default_constants.jsonx:6).
  *
+ *   ldpc::bp_simulation_throughput_t() the same harness in THROUGHPUT mode: channel noise drawn on the GPUs (counter-based Philox
+ *                                      keyed by the global frame index), frames sharded over `devices` behind the C-ABI
+ *                                      (ldpc_hip_open_multi: one host thread + stream per GPU, RCCL all-reduce of the counters),
+ *                                      upstream's sequential stopping rule replayed over the ordered per-frame records;
+ *   LDPC_HIP_DEVICES="0,1,2,3" | "all" selects the GPUs for every entry point below that takes no explicit list.
  *   ldpc::bp_simulation_t<Mat, Env>()  generic over the matrix type (needs n_rows(), n_cols(), operator()(i,j))
  *                                      and over the environment that owns the generator (see RngEnv below);
  *   ldpc::bp_simulation()              standalone: ldpc::Matrix + the library's own generator (ldpc::reset_random).
@@ -21,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -51,6 +57,27 @@ std::mt19937 &random_generator();  // seeded on demand
 int next_random_int(int min_inclusive, int max_exclusive);
 double next_random_gaussian();
 
+// GPUs to shard over: LDPC_HIP_DEVICES = "all" or a comma separated list of HIP ordinals; otherwise {fallback}.
+inline std::vector<int> devices_from_env(int fallback = 0) {
+    std::vector<int> d;
+    if (const char *e = getenv("LDPC_HIP_DEVICES")) {
+        const std::string v(e);
+        if (v == "all") {
+            for (int i = 0, n = ldpc_hip_device_count(); i < n; ++i) d.push_back(i);
+        } else {
+            size_t pos = 0;
+            while (pos < v.size()) {
+                size_t end = v.find(',', pos);
+                if (end == std::string::npos) end = v.size();
+                if (end > pos) d.push_back(atoi(v.substr(pos, end - pos).c_str()));
+                pos = end + 1;
+            }
+        }
+    }
+    if (d.empty()) d.push_back(fallback);
+    return d;
+}
+
 struct OwnRngEnv {
     static std::mt19937 &generator() { return random_generator(); }
     static double gaussian() { return next_random_gaussian(); }
@@ -70,7 +97,7 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
                                           int n_frame_errors, int n_experiments, double snr,
                                           double reference_frame_error, int decoder_type, int modulation_type,
                                           int permutation_type, int punctured_blocks, int show_process,
-                                          SimCounters *counters_out = nullptr, int device = 0, long long max_batch = 4096,
+                                          SimCounters *counters_out, const std::vector<int> &devices, long long max_batch = 4096,
                                           int permutation_block = 128, int permutation_inter = 1) {
     if (q_mod != 2) Env::fail("bp_simulation: only binary codes (q_mod == 2) are built in ldpc-lib_amd");
     if (modulation_type != MODULATION_SKIP_ && modulation_type != MODULATION_QAM4_)
@@ -81,8 +108,10 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
 
     std::vector<int16_t> hd((size_t)b * c);
     for (int i = 0; i < b; ++i) for (int j = 0; j < c; ++j) hd[(size_t)i * c + j] = (int16_t)H(i, j);  // :359-361
-    ldpc_hip_ctx *ctx = nullptr;
-    if (ldpc_hip_open(decoder_type, b, c, M, hd.data(), device, &ctx) != 0) Env::fail(ldpc_hip_last_error());  // :353-355
+    ldpc_hip_multi *ctx = nullptr;   // one DEC_STATE per GPU; the batch of a round is cut into contiguous slices
+    if (devices.empty()) Env::fail("bp_simulation: empty device list");
+    if (ldpc_hip_open_multi(decoder_type, b, c, M, hd.data(), devices.data(), (int)devices.size(), &ctx) != 0) Env::fail(ldpc_hip_last_error());  // :353-355
+    max_batch *= (long long)devices.size();
 
     int out_type;  // :451-466
     switch (decoder_type) {
@@ -131,8 +160,8 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
             const int plen = M * punctured_blocks, pstart = n - plen;
             for (int i = pstart; i < pstart + plen; ++i) y[i] = init_val;                        // :702-709
         }
-        if (ldpc_hip_decode_host(ctx, llr.data(), B, max_iterations, DEC_DECISION_HARD, 0.8 /*MS_ALPHA*/, decword.data(),
-                                 iters.data(), 0) != 0)
+        if (ldpc_hip_decode_host_multi(ctx, llr.data(), B, max_iterations, DEC_DECISION_HARD, 0.8 /*MS_ALPHA*/, decword.data(),
+                                       iters.data(), 0) != 0)
             Env::fail(ldpc_hip_last_error());
         long long used = 0;
         for (long long f = 0; f < B; ++f) {                                                     // ordered replay of :591-823
@@ -159,9 +188,78 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
         }
         if (batch < max_batch) batch *= 4;
     }
-    ldpc_hip_close(ctx);                                                                         // :831
+    ldpc_hip_close_multi(ctx);                                                                   // :831
     if (counters_out) { counters_out->nse = nse; counters_out->nde = nde; counters_out->nue = nue; counters_out->experiment = experiment; counters_out->sum_abs_iters = sum_abs_iters; }
     return std::make_pair((double)nse / experiment / (n - r), (double)nde / experiment);         // :840
+}
+
+// the single-device form (device ordinal; LDPC_HIP_DEVICES overrides it)
+template <class Mat, class Env>
+std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_length, int max_iterations,
+                                          int n_frame_errors, int n_experiments, double snr,
+                                          double reference_frame_error, int decoder_type, int modulation_type,
+                                          int permutation_type, int punctured_blocks, int show_process,
+                                          SimCounters *counters_out = nullptr, int device = 0, long long max_batch = 4096,
+                                          int permutation_block = 128, int permutation_inter = 1) {
+    return bp_simulation_t<Mat, Env>(q_mod, H, tailbite_length, max_iterations, n_frame_errors, n_experiments, snr, reference_frame_error,
+                                     decoder_type, modulation_type, permutation_type, punctured_blocks, show_process, counters_out,
+                                     devices_from_env(device), max_batch, permutation_block, permutation_inter);
+}
+
+// Throughput mode.  Same arguments and return value as bp_simulation(); differences from exact-replay mode: the noise is the
+// device-side Philox stream (seed), every modulation_type 0..4 is available (QAM16+ as the evidently intended chain), and
+// `codewords` (optional, [ncw][n] 0/1 bytes) are really transmitted.  The stopping rule is upstream's, frame by frame in global
+// frame order (:591, :805-823), so the result equals a sequential loop over the same noise whatever the batch size or GPU count.
+template <class Mat, class Env>
+std::pair<double, double> bp_simulation_throughput_t(int q_mod, Mat const &H, int tailbite_length, int max_iterations, int n_frame_errors,
+                                                     long long n_experiments, double snr, double reference_frame_error, int decoder_type,
+                                                     int modulation_type, int permutation_type, int permutation_block, int permutation_inter,
+                                                     int punctured_blocks, int show_process, unsigned long long seed,
+                                                     const std::vector<int> &devices, SimCounters *counters_out = nullptr,
+                                                     long long batch_per_gpu = 16384, const unsigned char *codewords = nullptr, int ncw = 0) {
+    if (q_mod != 2) Env::fail("bp_simulation: only binary codes (q_mod == 2) are built in ldpc-lib_amd");
+    if (devices.empty()) Env::fail("bp_simulation: empty device list");
+    const int b = H.n_rows(), c = H.n_cols(), M = tailbite_length;
+    const long long r = (long long)b * M, n = (long long)c * M;
+    std::vector<int16_t> hd((size_t)b * c);
+    for (int i = 0; i < b; ++i) for (int j = 0; j < c; ++j) hd[(size_t)i * c + j] = (int16_t)H(i, j);
+    ldpc_hip_multi *m = nullptr;
+    if (ldpc_hip_open_multi(decoder_type, b, c, M, hd.data(), devices.data(), (int)devices.size(), &m) != 0) Env::fail(ldpc_hip_last_error());
+    if (ldpc_hip_multi_set_interleaver(m, permutation_type, permutation_block, permutation_inter) != 0) Env::fail(ldpc_hip_last_error());
+    if (ncw > 0 && ldpc_hip_multi_set_codewords(m, codewords, ncw) != 0) Env::fail(ldpc_hip_last_error());
+    const int nsh = (int)devices.size();
+    long long nse = 0, nue = 0, nde = 0, experiment = 0, sum_abs_iters = 0, first = 0;
+    std::vector<int32_t> info, iters;
+    bool stop = false;
+    long long batch = 1024;   // ramp up like the exact harness: short runs stop after few frames
+    while (!stop && nde < n_frame_errors && experiment <= n_experiments) {                       // :591
+        const long long room = n_experiments + 1 - experiment;
+        long long B = batch * nsh;
+        if (B > room) B = room;
+        info.resize((size_t)B); iters.resize((size_t)B);
+        if (ldpc_hip_frames_multi(m, snr, modulation_type, punctured_blocks, max_iterations, 0.8 /*MS_ALPHA*/, seed, first, B, batch,
+                                  info.data(), iters.data(), nullptr, nullptr) != 0)
+            Env::fail(ldpc_hip_last_error());
+        for (long long f = 0; f < B; ++f) {                                                      // ordered replay of :591-823
+            if (!(nde < n_frame_errors && experiment <= n_experiments)) { stop = true; break; }
+            ++experiment;
+            const int it = iters[(size_t)f];
+            sum_abs_iters += it < 0 ? -it : it;
+            if (info[(size_t)f] != 0) {                                                          // bit 30: any wrong bit (:805)
+                nse += info[(size_t)f] & ((1 << 30) - 1); ++nde;
+                if (it >= 0) ++nue;
+                if (show_process)
+                    printf("SNR=%5.3lf,step=%4d,s_ers=%d,f_ers=%d,u_ers=%d,BER=%5.3le,FER=%5.3le\n", snr, (int)experiment, (int)nse, (int)nde,
+                           (int)nue, (double)nse / experiment / (double)(n - r), (double)nde / experiment);
+                if (nde >= 10 && (double)nde / experiment > 2.5 * reference_frame_error) { stop = true; break; }   // :820
+            }
+        }
+        first += B;
+        if (batch < batch_per_gpu) batch = batch * 4 < batch_per_gpu ? batch * 4 : batch_per_gpu;
+    }
+    ldpc_hip_close_multi(m);
+    if (counters_out) { counters_out->nse = nse; counters_out->nde = nde; counters_out->nue = nue; counters_out->experiment = experiment; counters_out->sum_abs_iters = sum_abs_iters; }
+    return std::make_pair((double)nse / experiment / (double)(n - r), (double)nde / experiment);
 }
 
 // Standalone entry point with upstream's argument list (bp_simulation.h:9-27); coef_matrix / ncols2convert only

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDPC_HIP_ABI_VERSION 1
+#define LDPC_HIP_ABI_VERSION 2
 
 /* decoders.h:16-28 enum DEC_ID (only the binary decoders on the hot path are built) */
 #define LDPC_HIP_BP_DEC 0  /* bp_decod_qc_lm         decoders.cpp:1708 (Gallager BP, log domain) */
@@ -83,7 +83,10 @@ const char *ldpc_hip_last_launch(const ldpc_hip_ctx *ctx);
  *           (upstream decword[v] = soft<0, resp. soft<1.0 for SP), or NULL
  *   d_iters [B] int32 out: upstream return value, or NULL
  * Numerics: outputs equal upstream's on the same inputs bit for bit -- hard decisions, return values and soft values -- for
- * MS, LMS, IMS, SP, ASP and TASP (fp64 in upstream's operation order, no FMA contraction; exp() by glibc's algorithm);
+ * MS, LMS, IMS (no transcendental on their path) and for SP, ASP and TASP against an upstream built with glibc >= 2.28 on an
+ * FMA-capable x86-64 host (fp64 in upstream's operation order, no FMA contraction; exp() is evaluated with that glibc's own
+ * algorithm and evaluation order -- an upstream linked against another libm, e.g. MSVC's from the vs2005/vs2010 projects, may
+ * differ from it, and so from this library, in the last ulp of soft values; hard decisions and return values are expected equal);
  * BP: hard decisions and return values identical, soft values within rtol 1e-5 / atol 1e-7 (its exp / log are the device's).
  *   d_soft  [B][N] float64 out, or NULL: the a-posteriori values upstream writes to decword[] when decision==1
  *           (MS/LMS: LLR; SP: likelihood ratio = what upstream leaves in soft[])
@@ -109,24 +112,44 @@ int ldpc_hip_set_ims_params(ldpc_hip_ctx *ctx, double thr, int qbits, int dbits)
 int ldpc_hip_decode_host(ldpc_hip_ctx *ctx, double *llr, long long B, int maxiter, int decision, double alpha,
                          double *decword, int32_t *iters, int clobber_sp_input);
 
-/* Device-side channel front end, replaces bp_simulation.cpp:444-449,600-612,697-710 for the all-zero codeword
- * (bp_simulation.cpp:568): llr = -2*(sigma*g - 1)/sigma^2, g ~ N(0,1) from a counter-based Philox4x32-10 stream
- * keyed by (seed, global frame index, variable index), so the result does not depend on batch split or GPU
- * count.  modulation_type 0 = BPSK ("SKIP"), 1 = QAM4 (upstream formula with sigmaQAM).  The last
- * M*punctured_blocks LLRs are set to 0.5 (LLR-type decoders) or 0 (SP) exactly as upstream (sic, Q7). */
+/* ---- the transmit / receive chain around the decoder ------------------------------------------------------------------
+ * Upstream's frame loop sends codeword -> direct interleaver -> mapper -> AWGN -> soft demapper -> inverse interleaver ->
+ * puncturing -> decoder and counts decword[i] != codeword[i] (bp_simulation.cpp:566-577, 596-710, 731-759).  A context starts in
+ * upstream's shipped wiring -- the all-zero codeword (bp_simulation.cpp:568 overwrites the encoder's output) and
+ * permutation_type 0 (files/default_constants.jsonx:6) -- and the two setters below change that for every later channel /
+ * count / simulate call on the context. */
+
+/* Interleaver of the chain: Permutations_Open / Permutation_Init (direct_inverse_perm.cpp:139-783) with permutation_type 0..4,
+ * permutation_block, permutation_inter of bp_simulation.h:21-23; halfmlog follows the modulation of each call
+ * (bp_simulation.cpp:402-411).  Fails (and leaves the identity) when the mode does not accept this code shape. */
+int ldpc_hip_set_interleaver(ldpc_hip_ctx *ctx, int permutation_type, int permutation_block, int permutation_inter);
+/* Transmitted codewords: HOST array [ncw][N] of 0/1 bytes in decoder order (e.g. from ldpc_hip_encode_host); global frame f
+ * carries codeword f % ncw.  ncw == 0 returns to the all-zero codeword.  (Replaces the `codeword` vector of
+ * bp_simulation.cpp:506-568; upstream draws ONE random codeword per call and then zeroes it.) */
+int ldpc_hip_set_codewords(ldpc_hip_ctx *ctx, const uint8_t *codewords, int ncw);
+
+/* The chain from codeword to decoder input for frames [first_frame, first_frame + B), on the device:
+ *   modulation_type 0 BPSK ("SKIP"), 1 QAM4: llr = -2*(sigma*g + 2*bit - 1)/sigma^2 (bp_simulation.cpp:603,610, sigma :445 / :449);
+ *   2 / 3 / 4 = QAM16 / 64 / 256 (modulation.h:4-11): GrayPAM mapper (QAM_modulator.cpp:129-194), x + sigmaQAM*g fresh per frame
+ *   (the evidently intended chain), per-rail soft demapper with cut-off T (QAM_demodulator.cpp:203-561),
+ *   negated (:627-628); the last symbol is padded with zero bits (:575).
+ * Then y[i] = buffer[inverse[i]] (:684) and the last M*punctured_blocks LLRs are set to 0.5 (LLR-type decoders) or 0
+ * (probability-type) exactly as upstream (sic, Q7; :697-710) -- for EVERY modulation, with the punctured bitrate in sigma (:444).
+ * g ~ N(0,1) from a counter-based Philox4x32-10 stream keyed by (seed, global frame index, channel position), so the result
+ * does not depend on batch split, GPU count, interleaver or codeword. */
+int ldpc_hip_channel_llr_dev(ldpc_hip_ctx *ctx, double snr_db, int modulation_type, int punctured_blocks, double T, uint64_t seed,
+                             long long first_frame, long long B, double *d_llr, void *stream);
+/* Earlier names of the same chain: BPSK / QAM4 (T unused), and QAM16+ without puncturing. */
 int ldpc_hip_awgn_llr_dev(ldpc_hip_ctx *ctx, double snr_db, int modulation_type, int punctured_blocks,
                           uint64_t seed, long long first_frame, long long B, double *d_llr, void *stream);
-
-/* 16-QAM chain (QAM_modulator.cpp:142, bp_simulation.cpp:447-449,621-628, QAM_demodulator.cpp:203-275) as
- * evidently intended upstream: all-zero codeword -> constellation points, fresh
- * x + sigmaQAM*g per frame, per-rail soft demap with cut-off T, negated.  N must be a multiple of 4. */
 int ldpc_hip_awgn_qam16_llr_dev(ldpc_hip_ctx *ctx, double snr_db, double T, uint64_t seed, long long first_frame,
                                 long long B, double *d_llr, void *stream);
-/* The same chain for modulation_type 2 (QAM16), 3 (QAM64), 4 (QAM256) (enum MODULATION_TYPE, modulation.h:4-11;
- * QAM_demodulator.cpp:203-561; sigmaQAM bp_simulation.cpp:447-449).  When N is not a multiple of log2 Q the last symbol is
- * padded with zero bits like bp_simulation.cpp:575 and only its first bits are written.  Same noise keys as the 16-QAM entry. */
 int ldpc_hip_awgn_qam_llr_dev(ldpc_hip_ctx *ctx, int modulation_type, double snr_db, double T, uint64_t seed, long long first_frame,
                               long long B, double *d_llr, void *stream);
+
+/* Function-level mapper: QAM_modulator.cpp:142-194 QAM_modulator() for Q in {4,16,64,256}.  d_bits [ns][log2 Q] bytes 0/1 (first half
+ * of a symbol's bits = I rail, MSB first; upstream passes them as doubles) -> d_x [ns][2] (I, Q interleaved) PAM levels. */
+int ldpc_hip_qam_modulate_dev(int Q, const uint8_t *d_bits, long long ns, double *d_x, int device, void *stream);
 
 /* Function-level soft demapper: QAM_demodulator.cpp:99-566 Demodulate() for Q in {4,16,64,256}, out_type 0/1 (Q = 4: out_type 0 only).
  * d_x [ns][2] (I,Q interleaved) -> d_out [ns][log2 Q]. */
@@ -149,21 +172,53 @@ int ldpc_hip_interleaver_build(int b, int c, int M, int halfmlog, int mode, int 
 /* Applies a map to B frames resident on the device: d_out[f][i] = d_in[f][d_map[i]] (d_in != d_out). */
 int ldpc_hip_permute_dev(const double *d_in, double *d_out, long long B, int N, const int32_t *d_map, int device, void *stream);
 
-/* Error accounting, replaces bp_simulation.cpp:731-759,805-810 for the all-zero codeword.
+/* Error accounting, replaces bp_simulation.cpp:731-759,805-810: hard decisions against the transmitted codeword of each frame
+ * (global frame first_frame + f carried codeword (first_frame + f) % ncw; all-zero when none is set).
  *   d_frame_info [B] int32 out (or NULL): number of wrong information bits (index >= R) of the frame, with bit 30
  *                set when the frame has any wrong bit at all (so 0 == frame correct)
  *   d_counters [5] uint64 in/out (accumulated with atomics; caller zeroes): nse, nde, nue, frames, sum |iters| */
+int ldpc_hip_count_errors_cw_dev(ldpc_hip_ctx *ctx, const uint32_t *d_hard, const int32_t *d_iters, long long first_frame, long long B,
+                                 int32_t *d_frame_info, unsigned long long *d_counters, void *stream);
+/* Same with first_frame = 0 (enough for the all-zero codeword or a single codeword; EINVAL when several are set). */
 int ldpc_hip_count_errors_dev(ldpc_hip_ctx *ctx, const uint32_t *d_hard, const int32_t *d_iters, long long B,
                               int32_t *d_frame_info, unsigned long long *d_counters, void *stream);
 
-/* One fused Monte-Carlo batch on the device: noise -> decode -> count, frames [first_frame, first_frame+B).
- * Uses internal workspace sized for `B` (grown on demand).  counters[4] (host) receive this batch's
+/* One fused Monte-Carlo batch on the device: chain -> decode -> count, frames [first_frame, first_frame+B), with the
+ * context's interleaver and codewords.  Uses internal workspace (grown on demand).  counters[4] (host) receive this batch's
  * {nse, nde, nue, frames}; sum_abs_iters (host, may be NULL) the sum of |iters| for throughput accounting.
  * Synchronous.  No stopping rule here: the sequential stopping rule of bp_simulation.cpp:591,820 is applied
  * by the host layer on the ordered per-frame records (ldpc::bp_simulation). */
 int ldpc_hip_simulate(ldpc_hip_ctx *ctx, double snr_db, int modulation_type, int punctured_blocks, int maxiter,
                       double alpha, uint64_t seed, long long first_frame, long long B,
                       unsigned long long counters[4], unsigned long long *sum_abs_iters);
+
+/* ---- several GPUs of one node (bp_simulation's frame loop sharded; north_star: RCCL all-reduce for the counters only) ----
+ * One shard = one context + one HIP stream + one host thread.  devices[i] is the HIP ordinal of shard i; ordinals may repeat
+ * (logical shards on one GPU: results are identical, the counters are then summed on the host because RCCL does not accept one
+ * device twice in a communicator).  With distinct devices the five counters are all-reduced over RCCL (ncclAllReduce, uint64 sum,
+ * one 40-byte message per call); RCCL is dlopen()ed, LDPC_HIP_RCCL_PATH overrides the library.  Frames [first_frame,
+ * first_frame + B) are cut into consecutive batches of `batch` frames, batch k goes to shard k mod n; noise is keyed by the global
+ * frame index, so counters and records do not depend on n or batch. */
+typedef struct ldpc_hip_multi ldpc_hip_multi;
+int ldpc_hip_open_multi(int decoder_id, int rh, int nh, int M, const int16_t *hd, const int *devices, int n_shards, ldpc_hip_multi **out);
+void ldpc_hip_close_multi(ldpc_hip_multi *m);
+int ldpc_hip_multi_shards(const ldpc_hip_multi *m);
+ldpc_hip_ctx *ldpc_hip_multi_ctx(ldpc_hip_multi *m, int shard);      /* per-shard settings (ims params, bp chain, profiling) */
+const char *ldpc_hip_multi_reduction(const ldpc_hip_multi *m);      /* "rccl" or "host" */
+int ldpc_hip_multi_set_interleaver(ldpc_hip_multi *m, int permutation_type, int permutation_block, int permutation_inter);
+int ldpc_hip_multi_set_codewords(ldpc_hip_multi *m, const uint8_t *codewords, int ncw);
+int ldpc_hip_simulate_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha,
+                            uint64_t seed, long long first_frame, long long B, long long batch, unsigned long long counters[4],
+                            unsigned long long *sum_abs_iters);
+/* Same, and the ordered per-frame records for the sequential stopping rule (bp_simulation.cpp:591,820): HOST arrays
+ * frame_info[B] (as d_frame_info above) and iters[B] in global frame order; counters / sum_abs_iters may be NULL. */
+int ldpc_hip_frames_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha,
+                          uint64_t seed, long long first_frame, long long B, long long batch, int32_t *frame_info, int32_t *iters,
+                          unsigned long long counters[4], unsigned long long *sum_abs_iters);
+/* ldpc_hip_decode_host over the shards: contiguous slices of the batch, one host thread per shard (BP_DEC with the frame chain
+ * on is sequential by definition and runs on shard 0). */
+int ldpc_hip_decode_host_multi(ldpc_hip_multi *m, double *llr, long long B, int maxiter, int decision, double alpha, double *decword,
+                               int32_t *iters, int clobber_sp_input);
 
 /* Timing aid for bench.py: average duration in milliseconds of the decode kernel launches recorded with
  * HIP events on their own stream since the last reset (events are only recorded while enabled). */

@@ -9,7 +9,7 @@ callers for device memory, streams and torch.distributed -- never for the arithm
 There is deliberately no CPU fallback: importing works anywhere, but every compute entry point raises
 `LdpcHipError` when the HIP library or a GPU is missing.
 """
-from .binding import (DEC_ASP, DEC_BP, DEC_IMS, DEC_LMS, DEC_MS, DEC_SP, DEC_TASP, LdpcHip, LdpcHipError, build_library, library_path,  # noqa: F401
+from .binding import (DEC_ASP, DEC_BP, DEC_IMS, DEC_LMS, DEC_MS, DEC_SP, DEC_TASP, LdpcHip, LdpcHipError, LdpcHipMulti, build_library, library_path,  # noqa: F401
                       load_library)
 from .host import GpuFrameSource, bp_simulation, relift_base_matrix, replay_stopping_rule  # noqa: F401
 

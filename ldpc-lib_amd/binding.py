@@ -59,6 +59,9 @@ def load_library():
         rtc = os.path.join(os.path.dirname(torch.__file__), "lib", "libhiprtc.so")
         if os.path.exists(rtc):  # JIT with the hiprtc that matches the HIP runtime torch brought into this process
             os.environ.setdefault("LDPC_HIP_HIPRTC_PATH", rtc)
+        rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(rccl):  # likewise one RCCL per process (ldpc_hip_open_multi dlopen()s it)
+            os.environ.setdefault("LDPC_HIP_RCCL_PATH", rccl)
     except ImportError:
         pass
     path = library_path()
@@ -94,7 +97,25 @@ def load_library():
     lib.ldpc_hip_permute_dev.argtypes = [vp, vp, i64, i32, vp, i32, vp]
     lib.ldpc_hip_profile_enable.argtypes = [vp, i32]
     lib.ldpc_hip_profile_read.argtypes = [vp, C.POINTER(f64), C.POINTER(i64), i32]
-    if lib.ldpc_hip_abi_version() != 1:
+    lib.ldpc_hip_set_interleaver.argtypes = [vp, i32, i32, i32]
+    lib.ldpc_hip_set_codewords.argtypes = [vp, vp, i32]
+    lib.ldpc_hip_channel_llr_dev.argtypes = [vp, f64, i32, i32, f64, u64, i64, i64, vp, vp]
+    lib.ldpc_hip_qam_modulate_dev.argtypes = [i32, vp, i64, vp, i32, vp]
+    lib.ldpc_hip_count_errors_cw_dev.argtypes = [vp, vp, vp, i64, i64, vp, vp, vp]
+    lib.ldpc_hip_open_multi.argtypes = [i32, i32, i32, i32, vp, vp, i32, C.POINTER(vp)]
+    lib.ldpc_hip_close_multi.argtypes = [vp]
+    lib.ldpc_hip_close_multi.restype = None
+    lib.ldpc_hip_multi_shards.argtypes = [vp]
+    lib.ldpc_hip_multi_ctx.argtypes = [vp, i32]
+    lib.ldpc_hip_multi_ctx.restype = vp
+    lib.ldpc_hip_multi_reduction.argtypes = [vp]
+    lib.ldpc_hip_multi_reduction.restype = C.c_char_p
+    lib.ldpc_hip_multi_set_interleaver.argtypes = [vp, i32, i32, i32]
+    lib.ldpc_hip_multi_set_codewords.argtypes = [vp, vp, i32]
+    lib.ldpc_hip_simulate_multi.argtypes = [vp, f64, i32, i32, i32, f64, u64, i64, i64, i64, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.ldpc_hip_frames_multi.argtypes = [vp, f64, i32, i32, i32, f64, u64, i64, i64, i64, vp, vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.ldpc_hip_decode_host_multi.argtypes = [vp, vp, i64, i32, i32, f64, vp, vp, i32]
+    if lib.ldpc_hip_abi_version() != 2:
         raise LdpcHipError("libldpc_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -146,6 +167,19 @@ class LdpcHip:
         """BP_DEC: chain frames through upstream's uncleared syndrome array (include/ldpc_hip.h)."""
         _check(self.lib, self.lib.ldpc_hip_set_bp_chain(self.h, int(on), int(reset_carry)), "ldpc_hip_set_bp_chain")
 
+    def set_interleaver(self, permutation_type, permutation_block=128, permutation_inter=1):
+        """Bit interleaver between mapper / demapper and the code (permutation_type 0..4 of bp_simulation.h:21-23)."""
+        _check(self.lib, self.lib.ldpc_hip_set_interleaver(self.h, int(permutation_type), int(permutation_block), int(permutation_inter)),
+               "ldpc_hip_set_interleaver")
+
+    def set_codewords(self, codewords):
+        """Transmitted codewords uint8 [C, N] (frame f carries codeword f % C); None or empty = upstream's all-zero codeword."""
+        if codewords is None or len(codewords) == 0:
+            _check(self.lib, self.lib.ldpc_hip_set_codewords(self.h, None, 0), "ldpc_hip_set_codewords")
+            return
+        cw = np.ascontiguousarray(codewords, dtype=np.uint8).reshape(-1, self.N)
+        _check(self.lib, self.lib.ldpc_hip_set_codewords(self.h, cw.ctypes.data, cw.shape[0]), "ldpc_hip_set_codewords")
+
     def __del__(self):
         try:
             self.close()
@@ -185,26 +219,25 @@ class LdpcHip:
         """Device-side channel: modulation 0 BPSK, 1 QAM4 (upstream formulas), 2 / 3 / 4 the 16- / 64- / 256-QAM chain (as intended upstream)."""
         import torch
         llr = out if out is not None else torch.empty((B, self.N), dtype=torch.float64, device=self._dev())
-        if modulation >= 2:
-            rc = self.lib.ldpc_hip_awgn_qam_llr_dev(self.h, int(modulation), float(snr_db), float(T), int(seed), int(first_frame), int(B),
-                                                    llr.data_ptr(), _stream_ptr(stream))
-        else:
-            rc = self.lib.ldpc_hip_awgn_llr_dev(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(seed),
-                                                int(first_frame), int(B), llr.data_ptr(), _stream_ptr(stream))
-        _check(self.lib, rc, "ldpc_hip_awgn_llr_dev")
+        rc = self.lib.ldpc_hip_channel_llr_dev(self.h, float(snr_db), int(modulation), int(punctured_blocks), float(T), int(seed),
+                                               int(first_frame), int(B), llr.data_ptr(), _stream_ptr(stream))
+        _check(self.lib, rc, "ldpc_hip_channel_llr_dev")
         return llr
 
-    def count_errors(self, hard, iters, counters=None, want_frame_info=False, stream=None):
-        """counters: int64 CUDA tensor[5] accumulated in place: nse, nde, nue, frames, sum|iters| (bp_simulation.cpp:805-810)."""
+    channel_llr = awgn_llr   # the whole chain: codeword -> interleaver -> mapper -> AWGN -> demapper -> interleaver -> puncturing
+
+    def count_errors(self, hard, iters, counters=None, want_frame_info=False, stream=None, first_frame=0):
+        """counters: int64 CUDA tensor[5] accumulated in place: nse, nde, nue, frames, sum|iters| (bp_simulation.cpp:805-810);
+        hard decisions are compared with the codeword each frame carried (first_frame = global index of frame 0)."""
         import torch
         B = iters.shape[0]
         if counters is None:
             counters = torch.zeros(5, dtype=torch.int64, device=iters.device)
         info = torch.empty((B,), dtype=torch.int32, device=iters.device) if want_frame_info else None
-        rc = self.lib.ldpc_hip_count_errors_dev(self.h, hard.data_ptr(), iters.data_ptr(), B,
-                                                info.data_ptr() if info is not None else None, counters.data_ptr(),
-                                                _stream_ptr(stream))
-        _check(self.lib, rc, "ldpc_hip_count_errors_dev")
+        rc = self.lib.ldpc_hip_count_errors_cw_dev(self.h, hard.data_ptr(), iters.data_ptr(), int(first_frame), B,
+                                                   info.data_ptr() if info is not None else None, counters.data_ptr(),
+                                                   _stream_ptr(stream))
+        _check(self.lib, rc, "ldpc_hip_count_errors_cw_dev")
         return counters, info
 
     def simulate(self, snr_db, maxiter, seed, first_frame, B, modulation=0, punctured_blocks=0, alpha=0.8):
@@ -243,6 +276,93 @@ class LdpcHip:
         ms, n = C.c_double(), C.c_longlong()
         _check(self.lib, self.lib.ldpc_hip_profile_read(self.h, C.byref(ms), C.byref(n), 1 if reset else 0), "ldpc_hip_profile_read")
         return ms.value, n.value
+
+
+class LdpcHipMulti:
+    """One opened code on several GPUs of a node behind the C-ABI (ldpc_hip_open_multi): one context + stream + host thread per
+    shard, frames sharded by global frame index, the five counters all-reduced over RCCL (or summed on the host when shards
+    share a device)."""
+
+    def __init__(self, decoder_id, H, M, devices):
+        self.lib = load_library()
+        H = np.ascontiguousarray(H, dtype=np.int16)
+        self.rh, self.nh = H.shape
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        rc = self.lib.ldpc_hip_open_multi(int(decoder_id), self.rh, self.nh, int(M), H.ctypes.data, devs.ctypes.data, len(devs), C.byref(h))
+        _check(self.lib, rc, "ldpc_hip_open_multi")
+        self.h = h
+        self.N, self.R = self.nh * int(M), self.rh * int(M)
+        self.shards = self.lib.ldpc_hip_multi_shards(h)
+        self.reduction = self.lib.ldpc_hip_multi_reduction(h).decode()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ldpc_hip_close_multi(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_interleaver(self, permutation_type, permutation_block=128, permutation_inter=1):
+        _check(self.lib, self.lib.ldpc_hip_multi_set_interleaver(self.h, int(permutation_type), int(permutation_block), int(permutation_inter)),
+               "ldpc_hip_multi_set_interleaver")
+
+    def set_codewords(self, codewords):
+        if codewords is None or len(codewords) == 0:
+            _check(self.lib, self.lib.ldpc_hip_multi_set_codewords(self.h, None, 0), "ldpc_hip_multi_set_codewords")
+            return
+        cw = np.ascontiguousarray(codewords, dtype=np.uint8).reshape(-1, self.N)
+        _check(self.lib, self.lib.ldpc_hip_multi_set_codewords(self.h, cw.ctypes.data, cw.shape[0]), "ldpc_hip_multi_set_codewords")
+
+    def simulate(self, snr_db, maxiter, seed, first_frame, B, batch, modulation=0, punctured_blocks=0, alpha=0.8, records=False):
+        cnt = (C.c_ulonglong * 4)()
+        sit = C.c_ulonglong()
+        if records:
+            info = np.empty(B, dtype=np.int32)
+            its = np.empty(B, dtype=np.int32)
+            rc = self.lib.ldpc_hip_frames_multi(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(maxiter), float(alpha),
+                                                int(seed), int(first_frame), int(B), int(batch), info.ctypes.data, its.ctypes.data, cnt, C.byref(sit))
+            _check(self.lib, rc, "ldpc_hip_frames_multi")
+        else:
+            info = its = None
+            rc = self.lib.ldpc_hip_simulate_multi(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(maxiter), float(alpha),
+                                                  int(seed), int(first_frame), int(B), int(batch), cnt, C.byref(sit))
+            _check(self.lib, rc, "ldpc_hip_simulate_multi")
+        out = {"nse": cnt[0], "nde": cnt[1], "nue": cnt[2], "frames": cnt[3], "sum_abs_iters": sit.value}
+        if records:
+            out["frame_info"], out["iters"] = info, its
+        return out
+
+    def decode_host(self, llr, maxiter, decision=0, alpha=0.8, clobber_sp_input=True):
+        llr = np.array(llr, dtype=np.float64, order="C", copy=True)
+        B = llr.shape[0]
+        dec = np.empty((B, self.N), dtype=np.float64)
+        its = np.empty(B, dtype=np.int32)
+        rc = self.lib.ldpc_hip_decode_host_multi(self.h, llr.ctypes.data, B, int(maxiter), int(decision), float(alpha), dec.ctypes.data,
+                                                 its.ctypes.data, 1 if clobber_sp_input else 0)
+        _check(self.lib, rc, "ldpc_hip_decode_host_multi")
+        return dec, its, llr
+
+
+def qam_modulate(bits, Q, device=0, stream=None):
+    """Function-level mapper (QAM_modulator.cpp QAM_modulator): uint8 CUDA tensor bits[ns, log2 Q] -> float64 [ns, 2] (I, Q)."""
+    import torch
+    lib = load_library()
+    ns = bits.shape[0]
+    out = torch.empty((ns, 2), dtype=torch.float64, device=bits.device)
+    rc = lib.ldpc_hip_qam_modulate_dev(int(Q), bits.data_ptr(), ns, out.data_ptr(), device, _stream_ptr(stream))
+    _check(lib, rc, "ldpc_hip_qam_modulate_dev")
+    return out
 
 
 def encode(H, M, info_bits):

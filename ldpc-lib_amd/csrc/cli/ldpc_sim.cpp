@@ -7,9 +7,9 @@
 // the result record written per code (:574-606).  What it does not do: girth / ACE tracing (trace_matrix, out of scope:
 // `girth` is copied through), marking files (`_marking` must be "skip"), GF(q) codes (`_q_mod` > 2 are reported and skipped).
 //
-//   --throughput   device-side noise (counter-based Philox, not upstream's mt19937 stream): 10^6-10^7 frames/s; the stopping
-//                  rule is applied per batch of frames instead of per frame.
-//   --device N     GPU ordinal
+//   --throughput   device-side noise (counter-based Philox, not upstream's mt19937 stream): 10^6-10^7 frames/s per GPU; every
+//                  modulation_type 0..4 and permutation_type 0..4; upstream's stopping rule frame by frame over the ordered records
+//   --device N     GPU ordinal;  --devices 0,1,2,3 | all   shard the frames over several GPUs (RCCL all-reduce of the counters)
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -44,36 +44,17 @@ void reduce_shifts(ldpc::Matrix &H, int M) {
 
 struct Pair { double ber, fer; };
 
-// device-side noise: batches of frames until error_blocks errored frames or num_codewords frames (bp_simulation.cpp:591)
-Pair simulate_throughput(const ldpc::Matrix &H, int M, int decoder_type, int iterations, int n_frame_errors, long long n_experiments,
-                         double snr, int modulation_type, int punctured_blocks, unsigned seed, int device) {
-    std::vector<int16_t> hd((size_t)H.n_rows() * H.n_cols());
-    for (size_t i = 0; i < hd.size(); ++i) hd[i] = (int16_t)H.v[i];
-    ldpc_hip_ctx *ctx = nullptr;
-    if (ldpc_hip_open(decoder_type, H.n_rows(), H.n_cols(), M, hd.data(), device, &ctx) != 0) die(ldpc_hip_last_error());
-    unsigned long long cnt[4] = {0, 0, 0, 0}, tot[4] = {0, 0, 0, 0}, sum_it = 0;
-    const long long batch = 16384;
-    long long first = 0;
-    while ((long long)tot[1] < n_frame_errors && (long long)tot[3] <= n_experiments) {
-        if (ldpc_hip_simulate(ctx, snr, modulation_type, punctured_blocks, iterations, MS_ALPHA, seed, first, batch, cnt, &sum_it) != 0)
-            die(ldpc_hip_last_error());
-        for (int i = 0; i < 4; ++i) tot[i] += cnt[i];
-        first += batch;
-    }
-    ldpc_hip_close(ctx);
-    const double n = (double)H.n_cols() * M, r = (double)H.n_rows() * M;
-    return {(double)tot[0] / (double)tot[3] / (n - r), (double)tot[1] / (double)tot[3]};
-}
-
 }  // namespace
 
 int main(int argc, char **argv) {
     bool throughput = false;
     int device = 0;
+    std::string devices_arg;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--throughput")) throughput = true;
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices_arg = argv[++i];
         else pos.push_back(argv[i]);
     }
     // jsonx utilities (no GPU needed): re-emit a file in canonical form / print one value addressed like upstream's select()
@@ -97,9 +78,12 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (pos.size() != 3 || pos[0] != "simulation")
-        die("usage: ldpc_sim simulation <scenario file name> <result file name> [--throughput] [--device N]\n"
+        die("usage: ldpc_sim simulation <scenario file name> <result file name> [--throughput] [--device N | --devices 0,1,.. | --devices all]\n"
             "       ldpc_sim jsonx <in.jsonx> <out.jsonx>        re-emit in canonical form\n"
             "       ldpc_sim jsonx-get <in.jsonx> <path/to/field>  print one value (falls back to 'defaults' records)");
+
+    if (!devices_arg.empty()) setenv("LDPC_HIP_DEVICES", devices_arg.c_str(), 1);
+    const std::vector<int> devices = ldpc::devices_from_env(device);
 
     try {
         const jsonx::Value scenario = jsonx::parse_file(pos[1]);
@@ -152,16 +136,17 @@ int main(int argc, char **argv) {
                 esn0[s] = snrs[s] + 10.0 * std::log10(2.0 * bitrate);                                                        // :481
                 Pair res;
                 if (throughput) {
-                    if (permutation_type != 0) die("--throughput: only permutation_type 0");
-                    res = simulate_throughput(H, lifting, decoder_type, iterations, num_frame_errors, num_experiments, snrs[s],
-                                              modulation_type, punctured_blocks, (unsigned)seed, device);
+                    const std::pair<double, double> p = ldpc::bp_simulation_throughput_t<ldpc::Matrix, ldpc::OwnRngEnv>(
+                        2, H, lifting, iterations, num_frame_errors, num_experiments, snrs[s], error_rate_threshold, decoder_type, modulation_type,
+                        permutation_type, permutation_block, permutation_inter, punctured_blocks, 0, (unsigned long long)seed, devices);
+                    res = {p.first, p.second};
                 } else {
                     ldpc::initial_random_seed = seed;
                     ldpc::reset_random();                                                                                     // :483 all codes are tested with same noise
                     ldpc::Matrix coef;
                     const std::pair<double, double> p = ldpc::bp_simulation_t<ldpc::Matrix, ldpc::OwnRngEnv>(
                         2, H, lifting, iterations, num_frame_errors, (int)num_experiments, snrs[s], error_rate_threshold, decoder_type,
-                        modulation_type, permutation_type, punctured_blocks, 0, nullptr, device, 4096, permutation_block, permutation_inter);
+                        modulation_type, permutation_type, punctured_blocks, 0, nullptr, devices, 4096, permutation_block, permutation_inter);
                     (void)coef;
                     res = {p.first, p.second};
                 }

@@ -73,3 +73,22 @@ extern "C" int ldpc_bp_simulation_exact(int rh, int nh, const int *H, int M, int
     return ldpc_bp_simulation_exact_perm(rh, nh, H, M, max_iterations, n_frame_errors, n_experiments, snr, reference_frame_error,
                                          decoder_type, modulation_type, 0, 128, 1, punctured_blocks, seed, device, out, rng_next);
 }
+
+// Throughput mode (device-side noise, frames sharded over `devices`, upstream's sequential stopping rule on the ordered records).
+// devices == NULL: LDPC_HIP_DEVICES or device 0.  codewords: [ncw][nh*M] 0/1 bytes or NULL (all-zero codeword).
+extern "C" int ldpc_bp_simulation_throughput(int rh, int nh, const int *H, int M, int max_iterations, int n_frame_errors,
+                                             long long n_experiments, double snr, double reference_frame_error, int decoder_type,
+                                             int modulation_type, int permutation_type, int permutation_block, int permutation_inter,
+                                             int punctured_blocks, unsigned long long seed, const int *devices, int n_devices,
+                                             long long batch_per_gpu, const unsigned char *codewords, int ncw, double out[7]) {
+    ldpc::Matrix mat(rh, nh);
+    for (int i = 0; i < rh * nh; ++i) mat.v[(size_t)i] = H[i];
+    const std::vector<int> devs = devices && n_devices > 0 ? std::vector<int>(devices, devices + n_devices) : ldpc::devices_from_env(0);
+    ldpc::SimCounters cnt;
+    const std::pair<double, double> res = ldpc::bp_simulation_throughput_t<ldpc::Matrix, ldpc::OwnRngEnv>(
+        2, mat, M, max_iterations, n_frame_errors, n_experiments, snr, reference_frame_error, decoder_type, modulation_type, permutation_type,
+        permutation_block, permutation_inter, punctured_blocks, 0, seed, devs, &cnt, batch_per_gpu, codewords, ncw);
+    out[0] = res.first; out[1] = res.second; out[2] = (double)cnt.nse; out[3] = (double)cnt.nde; out[4] = (double)cnt.nue;
+    out[5] = (double)cnt.experiment; out[6] = (double)cnt.sum_abs_iters;
+    return 0;
+}

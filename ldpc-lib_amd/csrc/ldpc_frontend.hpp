@@ -1,9 +1,12 @@
 // ldpc_frontend.hpp -- channel front end and error accounting kernels around the decoders (gfx950).
 //
-//   awgn_llr_kernel        bp_simulation.cpp:444-449,600-612,697-710  (BPSK / QAM4 LLRs of the all-zero codeword)
-//   awgn_qam_llr_kernel<H> QAM_modulator.cpp:142 + bp_simulation.cpp:621-628 (as intended) + QAM_demodulator.cpp:203-561, 16/64/256-QAM
+//   channel_llr_kernel<H>  the whole transmit / receive chain of one frame, bp_simulation.cpp:566-577,596-710:
+//                          codeword -> direct interleaver -> mapper (H = 0: BPSK / QAM4 formula :603,:610; H = 2,3,4: GrayPAM
+//                          16/64/256-QAM, QAM_modulator.cpp:129-194) -> AWGN -> soft demapper (QAM_demodulator.cpp:203-561,
+//                          negated :627-628) -> inverse interleaver (:684) -> puncturing (:697-710)
+//   qam_modulate_kernel    QAM_modulator.cpp:142-194 QAM_modulator(), function level
 //   qam_demod_kernel       QAM_demodulator.cpp:99-566 Demodulate(), Q in {4,16,64,256}
-//   count_errors_kernel    bp_simulation.cpp:731-759,805-810
+//   count_errors_kernel    bp_simulation.cpp:731-759,805-810 (against the transmitted codeword)
 //
 // These are streaming, HBM-bound byte/word kernels: one element (pair) per lane, coalesced 8/16-byte accesses,
 // grid-stride loops; no LDS.  Noise comes from a counter-based Philox4x32-10 generator keyed by
@@ -63,41 +66,6 @@ __device__ __forceinline__ void gauss_pair(uint64_t seed, uint64_t frame, uint32
     sincospi(2.0 * u2, &s, &c);
     g0 = rad * c;
     g1 = rad * s;
-}
-
-struct AwgnArgs {
-    double *llr;            // [B][N]
-    long long B, first_frame;
-    int N, punct_start;     // LLR index where the punctured tail begins (N when nothing is punctured)
-    double sigma;           // bp_simulation.cpp:445 (BPSK) or :449 (QAM4)
-    double punct_val;       // :700
-    uint64_t seed;
-};
-
-// llr = -2.0 * (sigma*g + 2.0*cw - 1.0) / (sigma*sigma), cw == 0   (bp_simulation.cpp:603 / :610)
-__global__ void __launch_bounds__(256) awgn_llr_kernel(const AwgnArgs a) {
-    const int pairs = (a.N + 1) >> 1;
-    const long long total = a.B * (long long)pairs;
-    const double s2 = a.sigma * a.sigma;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const long long b = i / pairs;
-        const int p = (int)(i - b * pairs);
-        double g0, g1;
-        gauss_pair(a.seed, (uint64_t)(a.first_frame + b), (uint32_t)p, 0u, g0, g1);
-        const int v = 2 * p;
-        double l0 = -2.0 * (a.sigma * g0 + 2.0 * 0.0 - 1.0) / s2;
-        double l1 = -2.0 * (a.sigma * g1 + 2.0 * 0.0 - 1.0) / s2;
-        if (v >= a.punct_start) l0 = a.punct_val;
-        if (v + 1 >= a.punct_start) l1 = a.punct_val;
-        double *row = a.llr + b * (long long)a.N;
-        if (v + 1 < a.N && ((a.N & 1) == 0)) {
-            *reinterpret_cast<double2 *>(row + v) = make_double2(l0, l1);  // 16-byte store, rows stay 16-B aligned
-        } else {
-            row[v] = l0;
-            if (v + 1 < a.N) row[v + 1] = l1;
-        }
-    }
 }
 
 // ---- soft demapper --------------------------------------------------------------------------------------
@@ -194,43 +162,93 @@ __global__ void __launch_bounds__(256) qam_demod_kernel(const DemodArgs a) {
     }
 }
 
-struct QamArgs {
-    double *llr;  // [B][N]
+// anti-Gray PAM labelling of QAM_modulator.cpp:127-139: level = 2*gray[x] - (2^order - 1), x = the rail's bits MSB first
+__device__ __forceinline__ int gray_pam_level(int x, int order) {
+    const unsigned long long gray = 0xAB98DCEF54672310ull;   // nibble x of {0,1,3,2,7,6,4,5,15,14,12,13,8,9,11,10}
+    return 2 * (int)((gray >> (4 * x)) & 15ull) - ((1 << order) - 1);
+}
+
+struct ChannelArgs {
+    double *llr;            // [B][N] out, decoder order
+    const uint8_t *tx;      // [ncw][ntx] transmitted bits in CHANNEL order (after the direct interleaver, zero padded to whole
+                            // symbols), or null = the all-zero codeword upstream sends (bp_simulation.cpp:568)
+    const int32_t *scatter; // [N] decoder index of channel bit j (= the direct map: y[i] = buffer[inverse[i]], :684), or null = identity
     long long B, first_frame;
-    int N;
-    double sigma, T;
+    int N, ntx, ncw;
+    int punct_start;        // decoder index where the punctured tail begins (N when nothing is punctured)
+    double sigma;           // bp_simulation.cpp:445 (BPSK) or :449 (QAM)
+    double punct_val;       // :700
+    double T;               // demapper cut-off (QAM16+)
     uint64_t seed;
 };
 
-// all-zero codeword -> every symbol is gray[0] on both rails = level 2*0 - (SQ-1) (QAM_modulator.cpp:127-139); the tail of
-// the last symbol is padded with zero bits (bp_simulation.cpp:575); received = symbol + sigmaQAM*g (fresh per frame);
-// LLR = -Demodulate(...) (bp_simulation.cpp:626-628).  H = bits per rail: 2 (16-QAM), 3 (64-QAM), 4 (256-QAM).
+// H = 0: one Box-Muller pair -> two BPSK / QAM4 LLRs, llr = -2.0 * (sigma*g + 2.0*bit - 1.0) / (sigma*sigma) (:603 / :610).
+// H = 2, 3, 4: one pair -> the two rails of one 16/64/256-QAM symbol: x = GrayPAM(bits) + sigmaQAM*g (fresh per frame, the
+// evidently intended chain), LLR = -Demodulate(x) (:626-628); the last symbol's missing bits are zero
+// (:575) and only the first N LLRs are kept.  Noise keys: (seed, global frame, pair or symbol index, tag 0 / 1) -- independent of
+// batching, sharding, interleaver and codeword.
 template <int H>
-__global__ void __launch_bounds__(256) awgn_qam_llr_kernel(const QamArgs a) {
-    constexpr int m = 2 * H;
-    const int ns = (a.N + m - 1) / m;
-    const long long total = a.B * (long long)ns;
-    const double N0 = 2.0 * a.sigma * a.sigma;
-    const double corner = -(double)((1 << H) - 1);
+__global__ void __launch_bounds__(256) channel_llr_kernel(const ChannelArgs a) {
+    constexpr int m = H == 0 ? 2 : 2 * H;           // channel bits per noise pair
+    const int units = (a.N + m - 1) / m;
+    const long long total = a.B * (long long)units;
+    const double s2 = a.sigma * a.sigma, N0 = 2.0 * s2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const long long b = i / ns;
-        const int s = (int)(i - b * ns);
+        const long long b = i / units;
+        const int u = (int)(i - b * units);
         double g0, g1;
-        gauss_pair(a.seed, (uint64_t)(a.first_frame + b), (uint32_t)s, 1u, g0, g1);
-        double bit[m], bi[H], bq[H];
-        demod_rail<H>(corner + a.sigma * g0, N0, a.T, 0, bi);
-        demod_rail<H>(corner + a.sigma * g1, N0, a.T, 0, bq);
+        gauss_pair(a.seed, (uint64_t)(a.first_frame + b), (uint32_t)u, H == 0 ? 0u : 1u, g0, g1);
+        const uint8_t *tx = a.tx ? a.tx + (size_t)((a.first_frame + b) % a.ncw) * a.ntx + (size_t)m * u : nullptr;
+        double bit[m];
+        if constexpr (H == 0) {
+            const double c0 = tx ? (double)tx[0] : 0.0, c1 = (tx && 2 * u + 1 < a.ntx) ? (double)tx[1] : 0.0;
+            bit[0] = -2.0 * (a.sigma * g0 + 2.0 * c0 - 1.0) / s2;
+            bit[1] = -2.0 * (a.sigma * g1 + 2.0 * c1 - 1.0) / s2;
+        } else {
+            int xi = 0, xq = 0;
+            if (tx) {
 #pragma unroll
-        for (int h = 0; h < H; ++h) { bit[h] = -bi[h]; bit[H + h] = -bq[h]; }
-        double *o = a.llr + b * (long long)a.N + (long long)m * s;
-        if (m * s + m <= a.N && (a.N & 1) == 0) {
+                for (int h = 0; h < H; ++h) { xi = 2 * xi + tx[h]; xq = 2 * xq + tx[H + h]; }   // z1 = p * bits, p = {2^(H-1) .. 1}
+            }
+            double bi[H], bq[H];
+            demod_rail<H>((double)gray_pam_level(xi, H) + a.sigma * g0, N0, a.T, 0, bi);
+            demod_rail<H>((double)gray_pam_level(xq, H) + a.sigma * g1, N0, a.T, 0, bq);
 #pragma unroll
-            for (int h = 0; h < m; h += 2) *reinterpret_cast<double2 *>(o + h) = make_double2(bit[h], bit[h + 1]);   // 16-byte aligned: N and m even
+            for (int h = 0; h < H; ++h) { bit[h] = -bi[h]; bit[H + h] = -bq[h]; }
+        }
+        double *row = a.llr + b * (long long)a.N;
+        const int j0 = m * u;
+        if (!a.scatter && j0 + m <= a.N && (a.N & 1) == 0) {
+#pragma unroll
+            for (int h = 0; h < m; h += 2) {   // 16-byte stores: N and m even keep every pair aligned
+                const double v0 = j0 + h >= a.punct_start ? a.punct_val : bit[h], v1 = j0 + h + 1 >= a.punct_start ? a.punct_val : bit[h + 1];
+                *reinterpret_cast<double2 *>(row + j0 + h) = make_double2(v0, v1);
+            }
         } else {
 #pragma unroll
-            for (int h = 0; h < m; ++h) if (m * s + h < a.N) o[h] = bit[h];
+            for (int h = 0; h < m; ++h)
+                if (j0 + h < a.N) {
+                    const int o = a.scatter ? a.scatter[j0 + h] : j0 + h;
+                    row[o] = o >= a.punct_start ? a.punct_val : bit[h];
+                }
         }
+    }
+}
+
+// QAM_modulator() at function level: bits [ns][m] (0/1 bytes, I rail first, MSB first) -> x [ns][2] (I, Q)
+struct ModArgs {
+    const uint8_t *bits;
+    double *x;
+    long long ns;
+    int H;
+};
+__global__ void __launch_bounds__(256) qam_modulate_kernel(const ModArgs a) {
+    for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < a.ns; s += (long long)gridDim.x * blockDim.x) {
+        const uint8_t *b = a.bits + s * (2 * a.H);
+        int xi = 0, xq = 0;
+        for (int h = 0; h < a.H; ++h) { xi = 2 * xi + (b[h] & 1); xq = 2 * xq + (b[a.H + h] & 1); }
+        *reinterpret_cast<double2 *>(a.x + 2 * s) = make_double2((double)gray_pam_level(xi, a.H), (double)gray_pam_level(xq, a.H));
     }
 }
 
@@ -242,6 +260,9 @@ struct CountArgs {
     unsigned long long *counters;  // [5]: nse, nde, nue, frames, sum |iters|
     long long B;
     int hard_words, R;
+    const uint32_t *cw;    // [ncw][hard_words] transmitted codewords, packed like `hard`, or null = all-zero (bp_simulation.cpp:568)
+    int ncw;
+    long long first_frame; // global index of frame 0: frame f carried codeword (first_frame + f) % ncw
 };
 
 // One wavefront per frame: lanes read the frame's packed words coalesced, popcount, butterfly-reduce.
@@ -253,7 +274,8 @@ __global__ void __launch_bounds__(256) count_errors_kernel(const CountArgs a) {
     for (long long fr = (long long)blockIdx.x * 4 + wv; fr < a.B; fr += (long long)gridDim.x * 4) {
         uint32_t all = 0, info = 0;
         for (int w = lane; w < a.hard_words; w += 64) {
-            const uint32_t x = a.hard[fr * a.hard_words + w];
+            uint32_t x = a.hard[fr * a.hard_words + w];
+            if (a.cw) x ^= a.cw[(size_t)((a.first_frame + fr) % a.ncw) * a.hard_words + w];   // decword[i] != codeword[i] (:735-742)
             all += __popc(x);
             // information bits are indices >= R (bp_simulation.cpp:738)
             const int lo = 32 * w;

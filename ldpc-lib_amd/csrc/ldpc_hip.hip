@@ -158,6 +158,17 @@ const AotInstance kAot[] = {
 
 }  // namespace
 
+// What the probability-domain decoders leave in their input array (decoders.cpp:2611-2618): P(bit = 1) of the channel,
+// with the decoder's own exp (glibc's algorithm on the device).
+__global__ void __launch_bounds__(256) channel_prior_kernel(double *x, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double h = x[i] * 0.5;
+        const double y = h < 20.0 ? (h < -20.0 ? -20.0 : h) : 20.0;
+        const double e0 = ldpc_spec::exp_glibc(y), e1 = ldpc_spec::exp_glibc(-y);
+        x[i] = e1 / (e0 + e1);
+    }
+}
+
 struct ldpc_hip_ctx {
     int decoder_id = 0, device = 0;
     int rh = 0, nh = 0, M = 0, N = 0, R = 0, ne = 0, hard_words = 0;
@@ -203,6 +214,17 @@ struct ldpc_hip_ctx {
     unsigned long long *w_counters = nullptr;
     long long w_frames = 0;
     bool w_has_soft = false;
+    // simulation chain around the decoder (ldpc_hip_set_interleaver / ldpc_hip_set_codewords): default = upstream's shipped
+    // wiring, all-zero codeword and permutation_type 0
+    int perm_type = 0, perm_block = 128, perm_inter = 1;
+    std::vector<int> hd_int;              // the base matrix as opened (the interleaver builder reads it)
+    std::vector<uint8_t> codewords;       // [ncw][N] 0/1, decoder order
+    int ncw = 0;
+    int chain_mod = -1;                   // modulation_type the device-side chain tables below were built for (-1: stale)
+    int chain_ntx = 0;
+    uint8_t *d_tx = nullptr;              // [ncw][ntx] bits in channel order, zero padded to whole symbols
+    uint32_t *d_cw_packed = nullptr;      // [ncw][hard_words]
+    int32_t *d_scatter = nullptr;         // [N] decoder index of channel bit j
     // HIP-event timing of decode launches
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -335,6 +357,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
     c->decoder_id = decoder_id; c->device = device;
     c->rh = rh; c->nh = nh; c->M = M; c->N = nh * M; c->R = rh * M; c->ne = t.ne;
     c->hard_words = (c->N + 31) / 32;
+    c->hd_int.assign(hd, hd + (size_t)rh * nh);
     c->bp_carry.assign((size_t)rh * ((M + 63) / 64) * 2, 0u);
     const char *venv = getenv("LDPC_HIP_MS_VARIANT");
     c->variant = venv ? atoi(venv) : 2;
@@ -437,6 +460,9 @@ void ldpc_hip_close(ldpc_hip_ctx *c) {
     if (c->d_bp_stale) (void)hipFree(c->d_bp_stale);
     if (c->d_bp_synd) (void)hipFree(c->d_bp_synd);
     if (c->d_bp_idx) (void)hipFree(c->d_bp_idx);
+    if (c->d_tx) (void)hipFree(c->d_tx);
+    if (c->d_cw_packed) (void)hipFree(c->d_cw_packed);
+    if (c->d_scatter) (void)hipFree(c->d_scatter);
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete c;
 }
@@ -632,13 +658,12 @@ int ldpc_hip_decode_host(ldpc_hip_ctx *c, double *llr, long long B, int maxiter,
         }
     }
     if (sp && clobber_sp_input) std::memcpy(llr, soft.data(), sizeof(double) * nllr);  // decoders.cpp:1950,2124
-    if (tasp && clobber_sp_input) {  // decoders.cpp:2611-2618: soft[] is left holding P(bit = 1) of the channel
-        for (size_t i = 0; i < nllr; ++i) {
-            const double x = llr[i] * 0.5;
-            const double y = x < 20.0 ? (x < -20.0 ? -20.0 : x) : 20.0;
-            const double e0 = std::exp(y), e1 = std::exp(-y);
-            llr[i] = e1 / (e0 + e1);
-        }
+    if (tasp && clobber_sp_input) {  // decoders.cpp:2611-2618: soft[] is left holding P(bit = 1) of the channel -- same exp() as the decoder's
+        long long blocks = ((long long)nllr + 255) / 256;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(channel_prior_kernel, dim3((unsigned)blocks), dim3(256), 0, nullptr, c->w_llr, (long long)nllr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(llr, c->w_llr, sizeof(double) * nllr, hipMemcpyDeviceToHost));
     }
     return 0;
 }
@@ -666,52 +691,135 @@ static int awgn_sigma(const ldpc_hip_ctx *c, double snr_db, int modulation_type,
     return 0;
 }
 
-int ldpc_hip_awgn_llr_dev(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, uint64_t seed,
-                          long long first_frame, long long B, double *d_llr, void *stream_) {
-    if (!c || !d_llr || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_awgn_llr_dev: bad argument");
-    if (modulation_type != 0 && modulation_type != 1) return fail(LDPC_HIP_EUNSUPPORTED, "modulation_type %d (0 BPSK, 1 QAM4)", modulation_type);
-    if (B == 0) return 0;
-    if (int rc = set_device(c)) return rc;
-    ldpc::AwgnArgs a{};
-    if (int rc = awgn_sigma(c, snr_db, modulation_type, punctured_blocks, &a.sigma)) return rc;
-    a.llr = d_llr; a.B = B; a.first_frame = first_frame; a.N = c->N;
-    a.punct_start = c->N - c->M * punctured_blocks;
-    a.punct_val = (c->decoder_id == LDPC_HIP_SP_DEC || c->decoder_id == LDPC_HIP_TASP_DEC || c->decoder_id == LDPC_HIP_ASP_DEC) ? 0.0 : 0.5;  // :700 (sic), out_type :451-466
-    a.seed = seed;
-    const long long total = B * (long long)((c->N + 1) / 2);
-    long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(ldpc::awgn_llr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, a);
-    HIP_TRY(hipGetLastError());
+// Device tables of the transmit side for one modulation: the interleaver's scatter map and the codewords in channel order.
+static int prepare_chain(ldpc_hip_ctx *c, int modulation_type) {
+    if (c->chain_mod == modulation_type) return 0;
+    const int N = c->N, halfmlog = modulation_type <= 1 ? 1 : modulation_type;   // bp_simulation.cpp:402-411
+    const int m = modulation_type <= 1 ? 2 : 2 * modulation_type;
+    const int ntx = modulation_type <= 1 ? N : ((N + m - 1) / m) * m;           // extra_bits of :575, zero
+    if (c->d_tx) (void)hipFree(c->d_tx);
+    if (c->d_cw_packed) (void)hipFree(c->d_cw_packed);
+    if (c->d_scatter) (void)hipFree(c->d_scatter);
+    c->d_tx = nullptr; c->d_cw_packed = nullptr; c->d_scatter = nullptr; c->chain_mod = -1;
+    std::vector<int32_t> direct, inverse;
+    if (c->perm_type != 0) {
+        ldpc::Interleaver il;
+        std::string err;
+        if (!ldpc::build_interleaver(c->rh, c->nh, c->M, halfmlog, c->perm_type, c->perm_block, c->perm_inter, c->hd_int.data(), il, err))
+            return fail(LDPC_HIP_EUNSUPPORTED, "%s", err.c_str());
+        direct.assign(il.direct.begin(), il.direct.end());
+        inverse.assign(il.inverse.begin(), il.inverse.end());
+        std::vector<int32_t> scatter((size_t)N, -1);
+        for (int i = 0; i < N; ++i) {   // y[i] = buffer[inverse[i]] (bp_simulation.cpp:684)  <=>  y[scatter[j]] = buffer[j]
+            if (inverse[(size_t)i] < 0 || inverse[(size_t)i] >= N || scatter[(size_t)inverse[(size_t)i]] != -1)
+                return fail(LDPC_HIP_EUNSUPPORTED, "interleaver mode %d: the inverse map is not a permutation", c->perm_type);
+            scatter[(size_t)inverse[(size_t)i]] = i;
+        }
+        HIP_TRY(hipMalloc(&c->d_scatter, sizeof(int32_t) * (size_t)N));
+        HIP_TRY(hipMemcpy(c->d_scatter, scatter.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
+    }
+    if (c->ncw > 0) {
+        std::vector<uint8_t> tx((size_t)c->ncw * ntx, 0);
+        std::vector<uint32_t> packed((size_t)c->ncw * c->hard_words, 0u);
+        for (int w = 0; w < c->ncw; ++w) {
+            const uint8_t *cw = c->codewords.data() + (size_t)w * N;
+            for (int j = 0; j < N; ++j) tx[(size_t)w * ntx + j] = cw[direct.empty() ? j : direct[(size_t)j]] & 1;   // Permutation(.., 0, ..) :570
+            for (int v = 0; v < N; ++v) packed[(size_t)w * c->hard_words + (v >> 5)] |= (uint32_t)(cw[v] & 1) << (v & 31);
+        }
+        HIP_TRY(hipMalloc(&c->d_tx, tx.size()));
+        HIP_TRY(hipMemcpy(c->d_tx, tx.data(), tx.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&c->d_cw_packed, sizeof(uint32_t) * packed.size()));
+        HIP_TRY(hipMemcpy(c->d_cw_packed, packed.data(), sizeof(uint32_t) * packed.size(), hipMemcpyHostToDevice));
+    }
+    c->chain_ntx = ntx;
+    c->chain_mod = modulation_type;
     return 0;
 }
 
-int ldpc_hip_awgn_qam_llr_dev(ldpc_hip_ctx *c, int modulation_type, double snr_db, double T, uint64_t seed, long long first_frame,
-                              long long B, double *d_llr, void *stream_) {
-    if (!c || !d_llr || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_awgn_qam_llr_dev: bad argument");
-    if (modulation_type < 2 || modulation_type > 4)
-        return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_awgn_qam_llr_dev: modulation_type %d (2 QAM16, 3 QAM64, 4 QAM256)", modulation_type);
+int ldpc_hip_set_interleaver(ldpc_hip_ctx *c, int permutation_type, int permutation_block, int permutation_inter) {
+    if (!c) return fail(LDPC_HIP_EINVAL, "ldpc_hip_set_interleaver: null context");
+    if (permutation_type < 0 || permutation_type > 4) return fail(LDPC_HIP_EINVAL, "permutation_type %d (0..4)", permutation_type);
+    if (int rc = set_device(c)) return rc;
+    c->perm_type = permutation_type; c->perm_block = permutation_block; c->perm_inter = permutation_inter;
+    c->chain_mod = -1;
+    if (permutation_type != 0) {   // fail now, not at the first batch, when this mode does not accept the code shape
+        const int keep = c->ncw;
+        c->ncw = 0;
+        const int rc = prepare_chain(c, 0);
+        c->ncw = keep; c->chain_mod = -1;
+        if (rc) { c->perm_type = 0; return rc; }
+    }
+    return 0;
+}
+
+int ldpc_hip_set_codewords(ldpc_hip_ctx *c, const uint8_t *codewords, int ncw) {
+    if (!c || ncw < 0 || (ncw > 0 && !codewords)) return fail(LDPC_HIP_EINVAL, "ldpc_hip_set_codewords: bad argument");
+    c->codewords.assign(codewords, codewords + (size_t)ncw * c->N);
+    c->ncw = ncw;
+    c->chain_mod = -1;
+    return 0;
+}
+
+int ldpc_hip_channel_llr_dev(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, double T, uint64_t seed,
+                             long long first_frame, long long B, double *d_llr, void *stream_) {
+    if (!c || !d_llr || B < 0 || first_frame < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_channel_llr_dev: bad argument");
+    if (modulation_type < 0 || modulation_type > 4)
+        return fail(LDPC_HIP_EUNSUPPORTED, "modulation_type %d (0 BPSK, 1 QAM4, 2 QAM16, 3 QAM64, 4 QAM256)", modulation_type);
     if (B == 0) return 0;
     if (int rc = set_device(c)) return rc;
-    ldpc::QamArgs a{};
-    if (int rc = awgn_sigma(c, snr_db, modulation_type, 0, &a.sigma)) return rc;
+    ldpc::ChannelArgs a{};
+    if (int rc = awgn_sigma(c, snr_db, modulation_type, punctured_blocks, &a.sigma)) return rc;
+    if (int rc = prepare_chain(c, modulation_type)) return rc;
     a.llr = d_llr; a.B = B; a.first_frame = first_frame; a.N = c->N; a.T = T; a.seed = seed;
-    const int m = 2 * modulation_type;
+    a.tx = c->ncw > 0 ? c->d_tx : nullptr; a.ncw = c->ncw > 0 ? c->ncw : 1; a.ntx = c->chain_ntx;
+    a.scatter = c->d_scatter;
+    a.punct_start = c->N - c->M * punctured_blocks;
+    a.punct_val = (c->decoder_id == LDPC_HIP_SP_DEC || c->decoder_id == LDPC_HIP_TASP_DEC || c->decoder_id == LDPC_HIP_ASP_DEC) ? 0.0 : 0.5;  // :700 (sic), out_type :451-466
+    const int m = modulation_type <= 1 ? 2 : 2 * modulation_type;
     const long long total = B * (long long)((c->N + m - 1) / m);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t stream = (hipStream_t)stream_;
-    if (modulation_type == 2) hipLaunchKernelGGL(ldpc::awgn_qam_llr_kernel<2>, grid, block, 0, stream, a);
-    else if (modulation_type == 3) hipLaunchKernelGGL(ldpc::awgn_qam_llr_kernel<3>, grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(ldpc::awgn_qam_llr_kernel<4>, grid, block, 0, stream, a);
+    switch (modulation_type) {
+    case 0: case 1: hipLaunchKernelGGL(ldpc::channel_llr_kernel<0>, grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(ldpc::channel_llr_kernel<2>, grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(ldpc::channel_llr_kernel<3>, grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL(ldpc::channel_llr_kernel<4>, grid, block, 0, stream, a); break;
+    }
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int ldpc_hip_awgn_llr_dev(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, uint64_t seed,
+                          long long first_frame, long long B, double *d_llr, void *stream_) {
+    if (modulation_type != 0 && modulation_type != 1) return fail(LDPC_HIP_EUNSUPPORTED, "modulation_type %d (0 BPSK, 1 QAM4)", modulation_type);
+    return ldpc_hip_channel_llr_dev(c, snr_db, modulation_type, punctured_blocks, 26.0, seed, first_frame, B, d_llr, stream_);
+}
+
+int ldpc_hip_awgn_qam_llr_dev(ldpc_hip_ctx *c, int modulation_type, double snr_db, double T, uint64_t seed, long long first_frame,
+                              long long B, double *d_llr, void *stream_) {
+    if (modulation_type < 2 || modulation_type > 4)
+        return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_awgn_qam_llr_dev: modulation_type %d (2 QAM16, 3 QAM64, 4 QAM256)", modulation_type);
+    return ldpc_hip_channel_llr_dev(c, snr_db, modulation_type, 0, T, seed, first_frame, B, d_llr, stream_);
 }
 
 int ldpc_hip_awgn_qam16_llr_dev(ldpc_hip_ctx *c, double snr_db, double T, uint64_t seed, long long first_frame,
                                 long long B, double *d_llr, void *stream_) {
     return ldpc_hip_awgn_qam_llr_dev(c, 2, snr_db, T, seed, first_frame, B, d_llr, stream_);
+}
+
+int ldpc_hip_qam_modulate_dev(int Q, const uint8_t *d_bits, long long ns, double *d_x, int device, void *stream_) {
+    if (!d_bits || !d_x || ns < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_qam_modulate_dev: bad argument");
+    if (Q != 4 && Q != 16 && Q != 64 && Q != 256) return fail(LDPC_HIP_EUNSUPPORTED, "QAM-%d mapper not built (4, 16, 64, 256)", Q);
+    if (ns == 0) return 0;
+    HIP_TRY(hipSetDevice(device));
+    ldpc::ModArgs a{d_bits, d_x, ns, Q == 4 ? 1 : Q == 16 ? 2 : Q == 64 ? 3 : 4};
+    long long blocks = (ns + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(ldpc::qam_modulate_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int ldpc_hip_qam_demod_dev(int Q, double T, double sigma, const double *d_x, long long ns, double *d_out,
@@ -770,14 +878,16 @@ int ldpc_hip_permute_dev(const double *d_in, double *d_out, long long B, int N, 
     return 0;
 }
 
-int ldpc_hip_count_errors_dev(ldpc_hip_ctx *c, const uint32_t *d_hard, const int32_t *d_iters, long long B,
-                              int32_t *d_frame_info, unsigned long long *d_counters, void *stream_) {
-    if (!c || !d_hard || !d_iters || !d_counters || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_count_errors_dev: bad argument");
+int ldpc_hip_count_errors_cw_dev(ldpc_hip_ctx *c, const uint32_t *d_hard, const int32_t *d_iters, long long first_frame, long long B,
+                                 int32_t *d_frame_info, unsigned long long *d_counters, void *stream_) {
+    if (!c || !d_hard || !d_iters || !d_counters || B < 0 || first_frame < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_count_errors_dev: bad argument");
     if (B == 0) return 0;
     if (int rc = set_device(c)) return rc;
+    if (c->ncw > 0 && c->chain_mod < 0) { if (int rc = prepare_chain(c, 0)) return rc; }   // the packed codewords do not depend on the modulation
     ldpc::CountArgs a{};
     a.hard = d_hard; a.iters = d_iters; a.frame_info = d_frame_info; a.counters = d_counters;
     a.B = B; a.hard_words = c->hard_words; a.R = c->R;
+    a.cw = c->ncw > 0 ? c->d_cw_packed : nullptr; a.ncw = c->ncw > 0 ? c->ncw : 1; a.first_frame = first_frame;
     long long blocks = (B + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(ldpc::count_errors_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, a);
@@ -785,24 +895,48 @@ int ldpc_hip_count_errors_dev(ldpc_hip_ctx *c, const uint32_t *d_hard, const int
     return 0;
 }
 
+int ldpc_hip_count_errors_dev(ldpc_hip_ctx *c, const uint32_t *d_hard, const int32_t *d_iters, long long B,
+                              int32_t *d_frame_info, unsigned long long *d_counters, void *stream_) {
+    if (c && c->ncw > 1) return fail(LDPC_HIP_EINVAL, "ldpc_hip_count_errors_dev: several codewords are set, the frame index is needed: use ldpc_hip_count_errors_cw_dev");
+    return ldpc_hip_count_errors_cw_dev(c, d_hard, d_iters, 0, B, d_frame_info, d_counters, stream_);
+}
+
+}  // extern "C"
+
+namespace {
+
+// One Monte-Carlo pass over frames [first_frame, first_frame + B) on `stream`: channel -> decode -> count, in chunks of the
+// workspace.  Counters accumulate into c->w_counters (caller zeroes); d_frame_info / d_iters_out (device, [B]) receive the
+// ordered per-frame records when not null.  Asynchronous except for BP_DEC with the chain on.
+int sim_enqueue(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha, uint64_t seed,
+                long long first_frame, long long B, int32_t *d_frame_info, int32_t *d_iters_out, hipStream_t stream) {
+    const long long chunk_max = 1 << 16;
+    const long long chunk = B < chunk_max ? B : chunk_max;
+    if (chunk > 0) { if (int rc = ensure_workspace(c, chunk, false)) return rc; }
+    for (long long done = 0; done < B; done += chunk) {
+        const long long nb = (B - done) < chunk ? (B - done) : chunk;
+        int rc = ldpc_hip_channel_llr_dev(c, snr_db, modulation_type, punctured_blocks, 26.0, seed, first_frame + done, nb, c->w_llr, stream);
+        if (rc) return rc;
+        int32_t *it = d_iters_out ? d_iters_out + done : c->w_iters;
+        if ((rc = ldpc_hip_decode_dev(c, c->w_llr, nb, maxiter, alpha, c->w_hard, it, nullptr, stream))) return rc;
+        if ((rc = ldpc_hip_count_errors_cw_dev(c, c->w_hard, it, first_frame + done, nb, d_frame_info ? d_frame_info + done : nullptr,
+                                               c->w_counters, stream)))
+            return rc;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
 int ldpc_hip_simulate(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, int maxiter,
                       double alpha, uint64_t seed, long long first_frame, long long B, unsigned long long counters[4],
                       unsigned long long *sum_abs_iters) {
     if (!c || !counters || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_simulate: bad argument");
     if (int rc = set_device(c)) return rc;
-    const long long chunk_max = 1 << 16;
-    const long long chunk = B < chunk_max ? B : chunk_max;
-    if (chunk > 0) { if (int rc = ensure_workspace(c, chunk, false)) return rc; }
     HIP_TRY(hipMemsetAsync(c->w_counters, 0, sizeof(unsigned long long) * 8, nullptr));
-    for (long long done = 0; done < B; done += chunk) {
-        const long long nb = (B - done) < chunk ? (B - done) : chunk;
-        int rc;
-        if (modulation_type >= 2) rc = ldpc_hip_awgn_qam_llr_dev(c, modulation_type, snr_db, 26.0, seed, first_frame + done, nb, c->w_llr, nullptr);
-        else rc = ldpc_hip_awgn_llr_dev(c, snr_db, modulation_type, punctured_blocks, seed, first_frame + done, nb, c->w_llr, nullptr);
-        if (rc) return rc;
-        if ((rc = ldpc_hip_decode_dev(c, c->w_llr, nb, maxiter, alpha, c->w_hard, c->w_iters, nullptr, nullptr))) return rc;
-        if ((rc = ldpc_hip_count_errors_dev(c, c->w_hard, c->w_iters, nb, nullptr, c->w_counters, nullptr))) return rc;
-    }
+    if (int rc = sim_enqueue(c, snr_db, modulation_type, punctured_blocks, maxiter, alpha, seed, first_frame, B, nullptr, nullptr, nullptr)) return rc;
     unsigned long long h[8];
     HIP_TRY(hipMemcpy(h, c->w_counters, sizeof h, hipMemcpyDeviceToHost));
     counters[0] = h[0]; counters[1] = h[1]; counters[2] = h[2]; counters[3] = h[3];
@@ -843,3 +977,5 @@ int ldpc_hip_profile_read(ldpc_hip_ctx *c, double *total_ms, long long *launches
 }
 
 }  // extern "C"
+
+#include "ldpc_multi.hpp"

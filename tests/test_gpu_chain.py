@@ -1,0 +1,328 @@
+"""GPU: the transmit / receive chain around the decoders and the multi-device layer behind the C-ABI.
+
+  * mapper against the compiled reference's vectors (tests/golden/qam_frontend.npz q*_bits -> q*_sym);
+  * codeword -> interleaver -> mapper -> AWGN -> demapper -> interleaver -> puncturing against a CPU twin (numpy Philox +
+    the oracle's mapper / demapper + upstream's interleaver maps);
+  * MS / LMS decisions mirror bit for bit under a codeword's sign flips; error counting against the sent word;
+  * random codewords through QAM-16 + interleaver mode 3 + min-sum: FER within Monte-Carlo spread of the all-zero run;
+  * ldpc_hip_open_multi: n = 1, 2, 8 logical shards give identical counters and ordered records; the RCCL leg on one rank.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from ldpc_testlib import (GOLDEN_DIR, LMS_DEC, MS_DEC, SP_DEC, Oracle, _as_double_p, load_base_matrix, oracle_lib, pack_bits,
+                          philox_gauss_pairs, relift, unpack_bits)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import ldpc_lib_amd
+    return ldpc_lib_amd
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _random_codewords(L, H, M, count, seed):
+    from ldpc_lib_amd.binding import encode
+    rng = np.random.RandomState(seed)
+    rh, nh = H.shape
+    return np.stack([encode(H, M, rng.randint(0, 2, size=(nh - rh) * M).astype(np.uint8)) for _ in range(count)])
+
+
+def test_mapper_equals_the_compiled_reference(L, torch):
+    """ldpc_hip_qam_modulate_dev == QAM_modulator() on the vectors the compiled upstream code produced."""
+    from ldpc_lib_amd.binding import qam_modulate
+    g = np.load(os.path.join(GOLDEN_DIR, "qam_frontend.npz"))
+    for Q, m in ((4, 2), (16, 4), (64, 6), (256, 8)):
+        bits = torch.from_numpy(g[f"q{Q}_bits"].astype(np.uint8).reshape(-1, m)).cuda()
+        sym = qam_modulate(bits, Q).cpu().numpy().ravel()
+        assert np.array_equal(sym, g[f"q{Q}_sym"]), Q
+        # and the oracle's restatement agrees (it is what the chain twin below uses)
+        want = np.zeros_like(g[f"q{Q}_sym"])
+        b = np.ascontiguousarray(g[f"q{Q}_bits"])
+        oracle_lib().orc_qam_modulate(Q, _as_double_p(b), len(b), _as_double_p(want))
+        assert np.array_equal(want, g[f"q{Q}_sym"])
+
+
+def _chain_twin(H, M, cws, first, B, seed, snr, mod, punct, perm, punct_val):
+    """CPU twin of ldpc_hip_channel_llr_dev: bp_simulation.cpp:566-577,596-710 with the device's Philox noise."""
+    from ldpc_lib_amd.binding import build_interleaver
+    rh, nh = H.shape
+    N = nh * M
+    rate = (nh - rh) / (nh - punct)
+    halfmlog = 1 if mod <= 1 else mod
+    m = 2 if mod <= 1 else 2 * mod
+    if perm is not None:
+        direct, inverse = build_interleaver(H, M, perm[0], halfmlog, perm[1], perm[2])
+    else:
+        direct = inverse = np.arange(N)
+    units = (N + m - 1) // m
+    out = np.zeros((B, N))
+    Q = 1 << (2 * mod) if mod >= 1 else 1
+    if mod == 0:
+        sigma = np.sqrt(10.0 ** (-snr / 10.0) / 2 / rate)
+    else:
+        sigma = np.sqrt(10.0 ** (-snr / 10.0) / (2 * rate * halfmlog * 2) * (2.0 * (Q - 1.0) / 3.0))
+    g = philox_gauss_pairs(seed, first + np.arange(B), units, tag=0 if mod <= 1 else 1)
+    for b in range(B):
+        cw = cws[(first + b) % len(cws)] if cws is not None else np.zeros(N, dtype=np.uint8)
+        tx = np.zeros(units * m)
+        tx[:N] = cw[direct]                                            # Permutation(.., 0, ..) :570, zero padding :575
+        if mod <= 1:
+            buf = -2.0 * (sigma * g[b, :N] + 2.0 * tx[:N] - 1.0) / (sigma * sigma)
+        else:
+            x = np.zeros(2 * units)
+            oracle_lib().orc_qam_modulate(Q, _as_double_p(np.ascontiguousarray(tx)), len(tx), _as_double_p(x))
+            x = np.ascontiguousarray(x + sigma * g[b])
+            dem = np.zeros(units * m)
+            oracle_lib().orc_qam_demodulate(Q, 26.0, float(sigma), _as_double_p(x), units, _as_double_p(dem), 0)
+            buf = -dem[:N]
+        y = buf[inverse]                                               # :684
+        if punct:
+            y[N - M * punct:] = punct_val                              # :697-710
+        out[b] = y
+    return out
+
+
+@pytest.mark.parametrize("mod,snr,punct,perm", [
+    (0, 1.5, 0, None), (0, 1.5, 2, (1, 128, 1)), (1, 2.0, 0, (3, 64, 1)),
+    (2, 6.0, 0, (3, 64, 1)), (2, 6.0, 3, None), (3, 10.0, 1, (2, 128, 1)), (4, 14.0, 0, (4, 128, 8)), (4, 14.0, 2, (1, 128, 1)),
+])
+def test_channel_chain_equals_its_cpu_twin(L, torch, mod, snr, punct, perm):
+    H = relift(load_base_matrix(), 64)
+    cws = _random_codewords(L, H, 64, 3, seed=11 + mod)
+    B, first, seed = 7, 4_000_000_123, (3 << 32) | 19
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        dec.set_codewords(cws)
+        if perm is not None:
+            dec.set_interleaver(*perm)
+        llr = dec.channel_llr(snr, seed, first, B, modulation=mod, punctured_blocks=punct).cpu().numpy()
+        ref = _chain_twin(H, 64, cws, first, B, seed, snr, mod, punct, perm, 0.5)
+        np.testing.assert_allclose(llr, ref, rtol=1e-9, atol=1e-9)
+        # most LLR signs agree with the transmitted word (it really was sent)
+        sent = np.stack([cws[(first + b) % 3] for b in range(B)])
+        keep = slice(0, 2048 - 64 * punct)
+        assert ((llr[:, keep] < 0) == (sent[:, keep] != 0)).mean() > 0.8
+        # back to upstream's wiring: the all-zero codeword, no interleaver
+        dec.set_codewords(None)
+        dec.set_interleaver(0)
+        llr0 = dec.channel_llr(snr, seed, first, B, modulation=mod, punctured_blocks=punct).cpu().numpy()
+        np.testing.assert_allclose(llr0, _chain_twin(H, 64, None, first, B, seed, snr, mod, punct, None, 0.5), rtol=1e-9, atol=1e-9)
+    with L.LdpcHip(SP_DEC, H, 64) as dec:   # probability-type decoders: punctured value 0 (sic, :700)
+        if punct:
+            llr = dec.channel_llr(snr, seed, first, 2, modulation=mod, punctured_blocks=punct).cpu().numpy()
+            assert (llr[:, 2048 - 64 * punct:] == 0.0).all()
+
+
+def test_decisions_mirror_under_the_codeword_and_are_counted_against_it(L, torch):
+    """BPSK: the LLRs of a transmitted codeword are the all-zero LLRs with the signs of the codeword's ones flipped (same noise),
+    min-sum and layered min-sum are odd-symmetric in that flip, so decword = decword_zero xor codeword, bit for bit, and the
+    error counters against the sent word equal the all-zero run's."""
+    H = relift(load_base_matrix(), 64)
+    cws = _random_codewords(L, H, 64, 5, seed=3)
+    B, first, seed, snr = 512, 1000, 77, 1.6
+    for dec_id in (MS_DEC, LMS_DEC):
+        with L.LdpcHip(dec_id, H, 64) as dec:
+            llr0 = dec.channel_llr(snr, seed, first, B)
+            h0, it0, _ = dec.decode(llr0, 50)
+            c0, info0 = dec.count_errors(h0, it0, want_frame_info=True, first_frame=first)
+            dec.set_codewords(cws)
+            llr1 = dec.channel_llr(snr, seed, first, B)
+            sent = torch.from_numpy(np.stack([cws[(first + b) % 5] for b in range(B)])).cuda()
+            assert torch.equal(llr1, torch.where(sent != 0, -llr0, llr0))
+            h1, it1, _ = dec.decode(llr1, 50)
+            c1, info1 = dec.count_errors(h1, it1, want_frame_info=True, first_frame=first)
+            torch.cuda.synchronize()
+            assert torch.equal(it0, it1)
+            want = h0.cpu().numpy().view(np.uint32) ^ pack_bits(sent.cpu().numpy().astype(np.float64))
+            assert np.array_equal(h1.cpu().numpy().view(np.uint32), want)
+            assert c0.cpu().tolist() == c1.cpu().tolist() and torch.equal(info0, info1)
+            assert c0[1].item() > 0                                   # there are errored frames to count at this Eb/N0
+            # fused path
+            s1 = dec.simulate(snr, 50, seed, first, B)
+            assert [s1["nse"], s1["nde"], s1["nue"], s1["frames"], s1["sum_abs_iters"]] == c1.cpu().tolist()
+
+
+def test_random_codewords_through_qam16_and_block_interleaver(L, torch):
+    """random codewords from ldpc_hip_encode_host through QAM-16 + interleaver mode 3 + min-sum; FER equals the
+    all-zero run's within Monte-Carlo spread (the channel is not sign-symmetric per bit under QAM-16, so not bit for bit)."""
+    H = relift(load_base_matrix(), 64)
+    cws = _random_codewords(L, H, 64, 16, seed=5)
+    B, snr = 40000, 5.2
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        dec.set_interleaver(3, 64, 1)
+        z = dec.simulate(snr, 50, seed=9, first_frame=0, B=B, modulation=2)
+        dec.set_codewords(cws)
+        r = dec.simulate(snr, 50, seed=9, first_frame=0, B=B, modulation=2)
+        # composition == fused, on a slice
+        llr = dec.channel_llr(snr, 9, 0, 2048, modulation=2)
+        hard, iters, _ = dec.decode(llr, 50)
+        cnt, _ = dec.count_errors(hard, iters, first_frame=0)
+        part = dec.simulate(snr, 50, seed=9, first_frame=0, B=2048, modulation=2)
+        assert [part["nse"], part["nde"], part["nue"], part["frames"], part["sum_abs_iters"]] == cnt.cpu().tolist()
+    fz, fr = z["nde"] / B, r["nde"] / B
+    assert 0.005 < fz < 0.3, fz
+    spread = 4.0 * np.sqrt(fz * (1 - fz) / B * 2)
+    assert abs(fz - fr) < spread, (fz, fr, spread)
+    # decoded words are codewords of the sent ones: bit errors stay a small fraction
+    assert r["nse"] / B / 1024 < 0.05
+
+
+def test_puncturing_applies_behind_every_modulation(L, torch):
+    """ldpc_hip_simulate with QAM16+ and punctured blocks uses the punctured bitrate and sets the tail (:444,697-710)."""
+    H = relift(load_base_matrix(), 64)
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        a = dec.simulate(7.0, 50, seed=4, first_frame=0, B=4096, modulation=2, punctured_blocks=0)
+        b = dec.simulate(7.0, 50, seed=4, first_frame=0, B=4096, modulation=2, punctured_blocks=2)
+        llr = dec.channel_llr(7.0, 4, 0, 4096, modulation=2, punctured_blocks=2)
+        hard, iters, _ = dec.decode(llr, 50)
+        cnt, _ = dec.count_errors(hard, iters)
+        assert [b["nse"], b["nde"], b["nue"], b["frames"], b["sum_abs_iters"]] == cnt.cpu().tolist()
+        assert (llr[:, 2048 - 128:] == 0.5).all()
+        assert b["sum_abs_iters"] != a["sum_abs_iters"]            # a different code rate and two erased blocks: not the same run
+
+
+# ---- several shards behind the C-ABI ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dec_id,M,mod,perm", [(MS_DEC, 64, 0, None), (LMS_DEC, 126, 1, (3, 126, 1)), (MS_DEC, 64, 2, (1, 128, 1))])
+def test_logical_shards_give_identical_results(L, torch, dec_id, M, mod, perm):
+    """n = 1, 2, 8 shards mapped to device 0: same counters, same ordered per-frame records, for any batch size; equal to the
+    single-context ldpc_hip_simulate."""
+    H = relift(load_base_matrix(), M)
+    snr, seed, first, B = (1.7 if mod < 2 else 5.5), 31, 5000, 3000
+    cws = _random_codewords(L, H, M, 4, seed=8)
+    with L.LdpcHip(dec_id, H, M) as dec:
+        dec.set_codewords(cws)
+        if perm:
+            dec.set_interleaver(*perm)
+        want = dec.simulate(snr, 50, seed, first, B, modulation=mod)
+        llr = dec.channel_llr(snr, seed, first, B, modulation=mod)
+        hard, iters, _ = dec.decode(llr, 50)
+        _, info = dec.count_errors(hard, iters, want_frame_info=True, first_frame=first)
+        want_info, want_it = info.cpu().numpy(), iters.cpu().numpy()
+    assert want["nde"] > 0
+    for n, batch in ((1, 1000), (2, 700), (8, 128), (8, 4096), (3, 333)):
+        with L.LdpcHipMulti(dec_id, H, M, [0] * n) as m:
+            assert m.shards == n and m.reduction == "host"
+            m.set_codewords(cws)
+            if perm:
+                m.set_interleaver(*perm)
+            got = m.simulate(snr, 50, seed, first, B, batch, modulation=mod, records=True)
+            for k in want:
+                assert got[k] == want[k], (n, batch, k)
+            assert np.array_equal(got["frame_info"], want_info) and np.array_equal(got["iters"], want_it)
+            got2 = m.simulate(snr, 50, seed, first, B, batch, modulation=mod)
+            assert all(got2[k] == want[k] for k in want)
+
+
+def test_counter_allreduce_through_rccl_on_one_rank(L, torch, monkeypatch):
+    """The RCCL leg (dlopen, ncclCommInitAll, ncclAllReduce of the five uint64 counters on the shard's stream) with a one-rank
+    communicator -- the only RCCL configuration a one-GPU box can run; n > 1 distinct devices take the same code path."""
+    monkeypatch.setenv("LDPC_HIP_RCCL_SINGLE", "1")
+    H = relift(load_base_matrix(), 64)
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        want = dec.simulate(1.5, 50, 2, 0, 5000)
+    with L.LdpcHipMulti(MS_DEC, H, 64, [0]) as m:
+        assert m.reduction == "rccl"
+        got = m.simulate(1.5, 50, 2, 0, 5000, 1024)
+        assert got == want
+        got = m.simulate(1.5, 50, 2, 0, 5000, 5000)                  # communicator reused across calls
+        assert got == want
+
+
+def test_decode_host_over_shards_and_exact_harness(L, torch):
+    """ldpc_hip_decode_host_multi (contiguous slices, one host thread per shard) == the single-context call; and the exact-replay
+    C++ harness run with LDPC_HIP_DEVICES=0,0,0 returns the sequential harness's counters and generator state."""
+    g = np.load(os.path.join(GOLDEN_DIR, "ms_m64_1p2.npz"))
+    H, M, maxiter = g["H"], int(g["M"]), int(g["maxiter"])
+    with L.LdpcHipMulti(MS_DEC, H, M, [0, 0, 0]) as m:
+        dec, its, _ = m.decode_host(g["llr"], maxiter)
+        assert np.array_equal(its, g["iters"]) and np.array_equal(pack_bits(dec), g["hard"])
+    from test_gpu_parity import _compat_lib
+    from ldpc_testlib import SimResult, c_int_p
+    lib = _compat_lib(L)
+    Hm = np.ascontiguousarray(relift(load_base_matrix(), 64), dtype=np.int32)
+    out = (C.c_double * 7)()
+    nxt = C.c_uint()
+    os.environ["LDPC_HIP_DEVICES"] = "0,0,0"
+    try:
+        assert lib.ldpc_bp_simulation_exact(16, 32, Hm.ctypes.data, 64, 50, 10**9, 1500, 1.2, 0.02, MS_DEC, 0, 0, 1, 0, C.addressof(out), C.addressof(nxt)) == 0
+    finally:
+        del os.environ["LDPC_HIP_DEVICES"]
+    res = SimResult()
+    assert oracle_lib().orc_bp_simulation(16, 32, Hm.ctypes.data_as(c_int_p), 64, 50, 10**9, 1500, 1.2, 0.02, MS_DEC, 0, 0, 1, C.byref(res), None) == 0
+    assert (out[2], out[3], out[4], out[5], out[6]) == (res.nse, res.nde, res.nue, res.experiment, res.sum_abs_iter)
+    assert nxt.value == res.rng_next
+
+
+@pytest.mark.parametrize("n_fe,n_exp,ref,devs,batch", [(10**9, 20000, 1.0, [0], 4096), (40, 10**7, 1.0, [0, 0], 1024), (10**9, 30000, 0.004, [0, 0, 0, 0], 512)])
+def test_cpp_throughput_harness_equals_the_python_harness(L, torch, n_fe, n_exp, ref, devs, batch):
+    """ldpc::bp_simulation_throughput_t (C++ over ldpc_hip_frames_multi) and ldpc_lib_amd.bp_simulation (Python over torch tensors)
+    replay the same sequential rule over the same device noise: identical counters whatever the sharding."""
+    from test_gpu_parity import _compat_lib
+    lib = _compat_lib(L)
+    H = np.ascontiguousarray(relift(load_base_matrix(), 64), dtype=np.int32)
+    out = (C.c_double * 7)()
+    d = (C.c_int * len(devs))(*devs)
+    lib.ldpc_bp_simulation_throughput.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_double, C.c_double,
+                                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ulonglong, C.c_void_p, C.c_int,
+                                                  C.c_longlong, C.c_void_p, C.c_int, C.c_void_p]
+    assert lib.ldpc_bp_simulation_throughput(16, 32, H.ctypes.data, 64, 50, n_fe, n_exp, 1.8, ref, MS_DEC, 0, 0, 128, 1, 0, 123, d, len(devs),
+                                             batch, None, 0, C.addressof(out)) == 0
+    ber, fer, st = L.bp_simulation(H, 64, 50, n_fe, n_exp, 1.8, ref, decoder_type=MS_DEC, seed=123, batch=3000, return_state=True)
+    assert (out[2], out[3], out[4], out[5], out[6]) == (st["nse"], st["nde"], st["nue"], st["experiment"], st["sum_abs_iters"])
+    assert out[0] == ber and out[1] == fer
+
+
+_RANK_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch, torch.distributed as dist
+import ldpc_lib_amd
+from ldpc_testlib import load_base_matrix, relift
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+H = relift(load_base_matrix(), 64)
+out = []
+for n_fe, n_exp, ref, batch in [(10**9, 6000, 1.0, 1024), (30, 10**6, 1.0, 500), (10**9, 20000, 0.004, 2048)]:
+    _, _, st = ldpc_lib_amd.bp_simulation(H, 64, 50, n_fe, n_exp, 1.8, ref, seed=123, batch=batch, return_state=True)
+    out.append([st["nse"], st["nde"], st["nue"], st["experiment"], st["sum_abs_iters"]])
+print("RESULT", dist.get_rank(), json.dumps(out))
+dist.destroy_process_group()
+"""
+
+
+def test_two_gpu_ranks_with_the_real_decoder(L, torch):
+    """The N > 1 path of ldpc_lib_amd.bp_simulation / bench.py with the REAL GpuFrameSource: two processes (both on this box's one
+    GPU, gloo for the record exchange) must each report the single-process result."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    H = relift(load_base_matrix(), 64)
+    want = []
+    for n_fe, n_exp, ref in [(10**9, 6000, 1.0), (30, 10**6, 1.0), (10**9, 20000, 0.004)]:
+        _, _, st = L.bp_simulation(H, 64, 50, n_fe, n_exp, 1.8, ref, seed=123, batch=4096, return_state=True)
+        want.append([st["nse"], st["nde"], st["nue"], st["experiment"], st["sum_abs_iters"]])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _RANK_WORKER.format(root=root)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for o in outs:
+        line = [ln for ln in o.splitlines() if ln.startswith("RESULT")][0]
+        assert json.loads(line.split(" ", 2)[2]) == want
