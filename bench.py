@@ -14,11 +14,20 @@ collective, per-GPU work fixed => "scaling": "weak".
 all 50 iterations (nothing is skipped by early termination); the reference's operating point 2.0 dB (FER ~4 %, early
 termination active, as upstream runs it) is reported next to it in "operating_point".
 
-roofline: SURVEY 8(d) algorithmic message-state bytes (77 824 B per frame-iteration of the (2048,1024) code) x
-iterations executed / decode-kernel time measured with HIP events on the launch stream.  NOTE: the kernel keeps that
-state in VGPRs/LDS, so `achieved` is an effective figure that can exceed the HBM peak; real HBM bytes are in "traffic".
+roofline (per kernel, also for every entry of "configs"):
+  achieved / peak / frac   SURVEY 8(d)'s ALGORITHMIC message-state bytes per frame-iteration x iterations executed / decode
+                           kernel time (HIP events on the launch stream) against the 8 TB/s HBM peak.  The decoders keep that
+                           state in VGPRs / LDS for all iterations, so this is an EFFECTIVE figure ("effective": true) and can
+                           exceed 1 -- it says how much HBM traffic the on-chip layout avoids, not how busy HBM is.
+  traffic / hbm_physical   HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 calibration in
+                           profiles/r02_fetch_calibration.txt, + WRITE_SIZE) and the physical HBM fraction they give.
+  valu_issue / lds         the BINDING roofs: vector instructions issued per second against the full-rate issue peak
+                           (one wave64 VALU instruction per 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz) and LDS-array busy cycles.
+PMC figures come from profiles/r02_pmc.json (tools/prof_pmc2.sh); they are used only when the kernel sources hash to the
+value recorded there, otherwise the fields are null.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -33,16 +42,95 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 M, MAXITER, ALPHA = 64, 50, 0.8
 FRAMES_PER_GPU = 65536
 WORST_SNR, OPER_SNR = 0.0, 2.0
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s spec
+CLOCK_HZ = 2.4e9         # max clock
+SIMDS, CUS = 1024, 256
+VALU_PEAK = SIMDS * CLOCK_HZ / 2.0   # wave64 VALU instructions per second at full rate (2 cycles each on a SIMD-32)
+
+DEC_BP, DEC_SP, DEC_ASP, DEC_MS, DEC_IMS, DEC_TASP, DEC_LMS = 0, 1, 2, 3, 4, 7, 8
 
 
-def ms_bytes_per_iter(E, R, N):
-    return 4.25 * E + 30 * R + 8.125 * N  # MS flooding, 4-byte LLR width
+def algorithmic_bytes_per_iter(formula, E, R, N):
+    """SURVEY 8(d) / BASELINE.md section 3: message-state bytes one decoder iteration touches (4-byte LLR width)."""
+    if formula == "ms":
+        return 4.25 * E + 30 * R + 8.125 * N
+    if formula == "lms":
+        return 12.25 * E + 20 * R
+    if formula == "sp":
+        return 16 * E + 8 * R + 8.125 * N
+    return None
+
+
+# The other configurations of BASELINE.json (and the f1 / f2 rows of SURVEY 8) on one GPU: timed in the same run as the headline
+# so that every number in DESIGN.md's table is driver-timed.  `frames` = one GPU's batch; worst case = 0 dB (all iterations run).
+EXTRA_CONFIGS = [
+    dict(key="cfg3_sum_product", dec=DEC_SP, M=64, frames=16384, maxiter=50, oper_snr=2.0, modulation=0, formula="sp",
+         what="(2048,1024) sum-product 50 it (BASELINE configs[2])"),
+    dict(key="cfg4_layered_m512", dec=DEC_LMS, M=512, frames=4096, maxiter=50, oper_snr=1.6, modulation=0, formula="lms",
+         what="(16384,8192) layered min-sum 50 it, one GPU's shard (BASELINE configs[3])"),
+    dict(key="cfg5_qam16_min_sum", dec=DEC_MS, M=64, frames=65536, maxiter=50, oper_snr=5.0, modulation=2, formula="ms",
+         what="(2048,1024) min-sum 50 it behind the 16-QAM mapper / soft demapper (BASELINE configs[4])"),
+    dict(key="f1_integer_min_sum", dec=DEC_IMS, M=64, frames=65536, maxiter=50, oper_snr=2.0, modulation=0, formula="ms",
+         what="(2048,1024) integer min-sum 50 it (SURVEY 8 f1)"),
+    dict(key="f2_tasp_m126", dec=DEC_TASP, M=126, frames=16384, maxiter=15, oper_snr=1.7, modulation=0, formula=None,
+         what="(4032,2016) M=126 TDMP sum-product 15 it, the shipped search scenario (SURVEY 8 f2)"),
+]
+
+
+def sources_hash():
+    """Hash of the kernel sources: PMC figures in profiles/r02_pmc.json are only quoted for the code they were measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ldpc-lib_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        p = os.path.join(d, fn)
+        if os.path.isfile(p) and fn.endswith((".hpp", ".hip")):
+            h.update(fn.encode())
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+    except Exception:
+        return {}, "profiles/r02_pmc.json missing"
+    if pj.get("sources_hash") != sources_hash():
+        return {}, f"profiles/r02_pmc.json was measured on sources {pj.get('sources_hash')}, this tree is {sources_hash()}"
+    return pj.get("kernels", {}), None
+
+
+def roofline_block(kernel_name, kernel_ms_avg, launches, sum_iters_per_launch, frames_per_launch, bytes_iter, pmc, pmc_why, pmc_key):
+    kern_s = kernel_ms_avg / 1e3
+    achieved = (sum_iters_per_launch * bytes_iter) / kern_s / 1e9 if (bytes_iter and kern_s > 0) else None
+    r = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
+        "effective": True, "traffic": None, "traffic_unit": "bytes per launch", "traffic_source": pmc_why,
+        "kernel": kernel_name, "kernel_ms_avg": kernel_ms_avg, "launches": launches,
+        "algorithmic_bytes_per_frame_iter": bytes_iter,
+        "algorithmic_bytes_per_launch": sum_iters_per_launch * bytes_iter if bytes_iter else None,
+        "binding_roof": None, "hbm_physical": None, "valu_issue": None, "lds": None,
+    }
+    p = pmc.get(pmc_key)
+    if p and kern_s > 0 and p.get("frames") == frames_per_launch:
+        hbm = (2.0 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0
+        wave_iters = p["wave_iterations"]
+        r["traffic"] = hbm
+        r["traffic_source"] = "profiles/r02_pmc.json (rocprofv3 --pmc, one pass per counter group, same launch shape; FETCH_SIZE x2 per profiles/r02_fetch_calibration.txt)"
+        r["hbm_physical"] = {"GBps": hbm / kern_s / 1e9, "frac": hbm / kern_s / 1e9 / HBM_PEAK_GBS, "bytes_per_frame": hbm / frames_per_launch}
+        r["valu_issue"] = {"valu_insts_per_launch": p["SQ_INSTS_VALU"], "valu_insts_per_wave_iter": p["SQ_INSTS_VALU"] / wave_iters,
+                           "cycles_per_inst": kern_s * CLOCK_HZ * SIMDS / p["SQ_INSTS_VALU"],
+                           "achieved_ginst_s": p["SQ_INSTS_VALU"] / kern_s / 1e9, "peak_ginst_s": VALU_PEAK / 1e9,
+                           "frac": p["SQ_INSTS_VALU"] / kern_s / VALU_PEAK}
+        r["lds"] = {"lds_insts_per_wave_iter": p["SQ_INSTS_LDS"] / wave_iters, "frac": p["SQ_LDS_IDX_ACTIVE"] / (kern_s * CLOCK_HZ * CUS),
+                    "bank_conflict_cycles": p["SQ_LDS_BANK_CONFLICT"]}
+        r["binding_roof"] = "valu_issue" if r["valu_issue"]["frac"] >= r["lds"]["frac"] else "lds"
+    return r
 
 
 def cpu_baseline(H, seconds_budget=12.0):
     """CPU decode-only timing on this host, on a bounded sample of the SAME workload (0 dB, 50 iterations/frame).
-    Uses the compiled upstream reference (oracle/_ref) when it travelled with the repo, else the C restatement."""
+    Uses the compiled upstream reference (oracle/_ref) when it travelled with the repo, else the C restatement.
+    Runs BEFORE anything touches the GPU (the workers are forked; a process that has initialised HIP must not fork)."""
     import multiprocessing as mp
 
     from ldpc_testlib import MS_DEC, Oracle, Reference, awgn_llr, ref_lib
@@ -85,7 +173,8 @@ def cpu_baseline(H, seconds_budget=12.0):
         "value": all_core if all_core is not None else one_core, "unit": "frames/s",
         "cores": cores if all_core is not None else 1, "kind": kind, "value_1core": one_core,
         "sample": f"{n1} frames single-thread + {cores}x same frames one process per core, (2048,1024) min-sum, "
-                  f"Eb/N0 {WORST_SNR} dB, all {MAXITER} iterations run (mean |iters| {float(np.abs(its).mean()):.1f}), decode only",
+                  f"Eb/N0 {WORST_SNR} dB, all {MAXITER} iterations run (mean |iters| {float(np.abs(its).mean()):.1f}), decode only, "
+                  "measured before the GPU was initialised",
     }
 
 
@@ -96,21 +185,32 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip operating point + FER sweep (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip operating point, FER sweep and the other configurations (profiling runs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI, the measured configuration); gloo only rehearses the N>1 code path on a box "
                          "with fewer GPUs than ranks (ranks then share devices and the counters are reduced on the host)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    from ldpc_testlib import load_base_matrix, relift
+    H = relift(load_base_matrix(), M)
+
+    # the CPU leg first: nothing has touched the GPU yet (no torch.cuda call, libldpc_hip.so not loaded)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(H)
+        except Exception as ex:  # the bench line must still be printed
+            cpu = {"value": None, "error": repr(ex)}
+
     import torch
     import torch.distributed as dist
 
     import ldpc_lib_amd
-    from ldpc_testlib import load_base_matrix
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
@@ -137,48 +237,44 @@ def main():
             dist.all_reduce(h, **kw)
             t.copy_(h)
 
-    H = ldpc_lib_amd.relift_base_matrix(load_base_matrix(), M)
-    B = args.frames
-    dec = ldpc_lib_amd.LdpcHip(ldpc_lib_amd.DEC_MS, H, M, device=local)
-    N, E, R = dec.N, dec.edges * M, dec.R
-    bytes_iter = ms_bytes_per_iter(E, R, N)
-
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def make_batches(snr, nb):
-        # distinct frames per step and per rank: global frame index = (step*world + rank)*B + i
-        return [dec.awgn_llr(snr, seed=1, first_frame=(s * world + rank) * B, B=B) for s in range(nb)]
+    pmc, pmc_why = load_pmc()
 
-    hard = torch.empty((B, dec.hard_words), dtype=torch.int32, device=dev)
-    iters = torch.empty((B,), dtype=torch.int32, device=dev)
-    cnt = torch.zeros(5, dtype=torch.int64, device=dev)
-
-    def step(llr, tot):
-        """decode one resident batch, count errors, (N > 1) all-reduce the five counters over RCCL/xGMI"""
-        dec.decode(llr, MAXITER, alpha=ALPHA, out=(hard, iters, None))
-        cnt.zero_()
-        dec.count_errors(hard, iters, counters=cnt)
-        if world > 1:
-            all_reduce(cnt)  # 40-byte message: {nse, nde, nue, frames, sum|iters|}
-        tot += cnt
-
-    def timed(snr, steps, warmup):
+    def timed(dec, B, snr, steps, warmup, maxiter, modulation=0):
+        """W warm-up + K timed steps (decode + count [+ all-reduce]) over batches resident in HBM; returns wall seconds (max over
+        ranks), the counter totals and the decode kernel's HIP-event time."""
         nb = min(max(steps, 1), 8)
-        batches = make_batches(snr, nb)
+        if B * dec.N * 8 * nb > 12e9:
+            nb = max(1, int(12e9 // (B * dec.N * 8)))
+        # distinct frames per step and per rank: global frame index = (step*world + rank)*B + i
+        batches = [dec.awgn_llr(snr, seed=1, first_frame=(s * world + rank) * B, B=B, modulation=modulation) for s in range(nb)]
+        hard = torch.empty((B, dec.hard_words), dtype=torch.int32, device=dev)
+        iters = torch.empty((B,), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(5, dtype=torch.int64, device=dev)
         tot = torch.zeros(5, dtype=torch.int64, device=dev)
+
+        def step(llr):
+            dec.decode(llr, maxiter, alpha=ALPHA, out=(hard, iters, None))
+            cnt.zero_()
+            dec.count_errors(hard, iters, counters=cnt)
+            if world > 1:
+                all_reduce(cnt)  # 40-byte message: {nse, nde, nue, frames, sum|iters|}
+            tot.add_(cnt)
+
         for s in range(warmup):
-            step(batches[s % nb], tot)
+            step(batches[s % nb])
         tot.zero_()
         dec.profile(True)
         dec.profile_read(reset=True)
         barrier()
         t0 = time.perf_counter()
         for s in range(steps):
-            step(batches[s % nb], tot)
+            step(batches[s % nb])
         barrier()
         el = time.perf_counter() - t0
         kms, klaunch = dec.profile_read(reset=True)
@@ -189,24 +285,16 @@ def main():
         del batches
         return float(t.item()), tot.cpu().tolist(), kms, klaunch
 
-    el, tot, kms, klaunch = timed(WORST_SNR, args.steps, args.warmup)
+    # ---------------- headline: BASELINE configs[1]
+    B = args.frames
+    dec = ldpc_lib_amd.LdpcHip(DEC_MS, H, M, device=local)
+    N, E, R = dec.N, dec.edges * M, dec.R
+    bytes_iter = algorithmic_bytes_per_iter("ms", E, R, N)
+    el, tot, kms, klaunch = timed(dec, B, WORST_SNR, args.steps, args.warmup, MAXITER)
     frames_total = tot[3]
     assert frames_total == B * args.steps * world, (frames_total, B, args.steps, world)
     value = frames_total / el
     sum_iters_rank = tot[4] / world  # every rank does the same amount of work (weak scaling)
-    kern_s = kms / 1e3
-    achieved = (sum_iters_rank * bytes_iter) / kern_s / 1e9 if kern_s > 0 else None
-
-    # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/prof_pmc.sh):
-    # bench.py cannot collect hardware counters itself, so the figure is reported with its provenance, and only when it
-    # was measured for the kernel and launch shape that just ran.
-    traffic, traffic_src = None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if tj["kernel"].split("(")[0] in dec.kernel_name and B == FRAMES_PER_GPU:
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_traffic.json: " + tj["source"]
-    except Exception:
-        pass
 
     out = {
         "metric": "decoded frames/sec, (2048,1024) QC-LDPC, 50 iters min-sum", "value": value, "unit": "frames/s",
@@ -219,21 +307,14 @@ def main():
             "frames_per_gpu_per_step": B, "global_frames_per_step": B * world, "sharding": f"frames x{world}", "collective": (args.backend + " all-reduce of 5 int64 counters per step") if world > 1 else None,
             "fer": tot[1] / tot[3], "mean_iters_per_frame": tot[4] / tot[3],
         },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic, "traffic_unit": "bytes per launch",
-            "traffic_source": traffic_src,
-            "kernel": dec.kernel_name, "kernel_ms_avg": kms / max(klaunch, 1), "launches": klaunch,
-            "algorithmic_bytes_per_frame_iter": bytes_iter,
-            "algorithmic_bytes_per_launch": sum_iters_rank * bytes_iter / max(klaunch, 1),
-            "note": "effective message-state bandwidth (SURVEY 8d); the state is VGPR/LDS resident, compulsory HBM bytes "
-                    f"per frame = {8 * N} (fp64 LLR in) + {N // 8 + 4} (packed bits + iters out); the kernel is bound by "
-                    "VALU issue (fp64 + half-rate VOP3/compare/select) with LDS ~48% busy, not by HBM (DESIGN.md 4.2)",
-        },
+        "roofline": roofline_block(dec.kernel_name, kms / max(klaunch, 1), klaunch, sum_iters_rank / max(klaunch, 1), B, bytes_iter, pmc, pmc_why, "cfg2_min_sum"),
     }
+    out["roofline"]["note"] = ("achieved = effective message-state bandwidth (SURVEY 8d): the state is VGPR/LDS resident, compulsory HBM bytes per frame = "
+                               f"{8 * N} (fp64 LLR in) + {N // 8 + 4} (packed bits + iters out); the binding roof is VALU issue "
+                               "(fp64 + half-rate VOP3 / compare / select), see valu_issue / lds / hbm_physical")
 
     if not args.no_extras:
-        el2, tot2, kms2, kl2 = timed(OPER_SNR, max(4, args.steps // 2), 1)
+        el2, tot2, kms2, kl2 = timed(dec, B, OPER_SNR, max(4, args.steps // 2), 1, MAXITER)
         out["operating_point"] = {
             "ebn0_db": OPER_SNR, "value": tot2[3] / el2, "unit": "frames/s", "fer": tot2[1] / tot2[3],
             "ber": tot2[0] / tot2[3] / (N - R), "mean_iters_per_frame": tot2[4] / tot2[3],
@@ -248,16 +329,34 @@ def main():
             c = c.cpu().tolist()
             sweep.append({"ebn0_db": float(snr), "fer": c[1] / c[2], "ber": c[0] / c[2] / (N - R), "frames": c[2]})
         out["fer_sweep"] = sweep
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline(H)
-        except Exception as ex:  # the bench line must still be printed
-            out["cpu_baseline"] = {"value": None, "error": repr(ex)}
-    elif rank == 0:
-        out["cpu_baseline"] = None
-
     dec.close()
+
+    # ---------------- the other configurations, same run, one GPU (N = 1 only: they are per-GPU figures)
+    if not args.no_extras and world == 1:
+        from ldpc_testlib import load_base_matrix as lbm
+        cfgs = {}
+        ksteps = max(3, min(args.steps, 6))
+        for c in EXTRA_CONFIGS:
+            Hc = relift(lbm(), c["M"])
+            try:
+                with ldpc_lib_amd.LdpcHip(c["dec"], Hc, c["M"], device=local) as d:
+                    bi = algorithmic_bytes_per_iter(c["formula"], d.edges * c["M"], d.R, d.N)
+                    e1, t1, k1, l1 = timed(d, c["frames"], WORST_SNR, ksteps, 1, c["maxiter"], c["modulation"])
+                    e2, t2, k2, l2 = timed(d, c["frames"], c["oper_snr"], ksteps, 1, c["maxiter"], c["modulation"])
+                    cfgs[c["key"]] = {
+                        "workload": c["what"], "frames_per_step": c["frames"], "steps": ksteps, "max_iterations": c["maxiter"],
+                        "worst_case": {"ebn0_db": WORST_SNR, "value": t1[3] / e1, "unit": "frames/s", "ms_per_step": e1 / ksteps * 1e3,
+                                       "mean_iters_per_frame": t1[4] / t1[3], "fer": t1[1] / t1[3]},
+                        "operating_point": {"ebn0_db": c["oper_snr"], "value": t2[3] / e2, "unit": "frames/s", "ms_per_step": e2 / ksteps * 1e3,
+                                            "mean_iters_per_frame": t2[4] / t2[3], "fer": t2[1] / t2[3], "kernel_ms_avg": k2 / max(l2, 1)},
+                        "roofline": roofline_block(d.kernel_name, k1 / max(l1, 1), l1, t1[4] / max(l1, 1), c["frames"], bi, pmc, pmc_why, c["key"]),
+                    }
+            except Exception as ex:
+                cfgs[c["key"]] = {"workload": c["what"], "error": repr(ex)}
+        out["configs"] = cfgs
+
+    out["cpu_baseline"] = cpu if (rank == 0 and world == 1) else None
+
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
