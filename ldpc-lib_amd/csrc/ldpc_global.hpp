@@ -1,0 +1,311 @@
+// ldpc_global.hpp -- the shape-unlimited tier: flooding min-sum and layered min-sum with the message state in GLOBAL memory.
+//
+// The LDS/VGPR-resident kernels (ldpc_spec.hpp, ldpc_kernels.hpp) need the a-posteriori values of a frame in one CU's LDS
+// (N * 8 B <= 160 KiB), M <= 512, <= 64 block rows / columns, row weight <= 16 and no empty block column.  Upstream's decod_open
+// (decoders.cpp:348-791) has none of these limits, so any other valid binary QC-LDPC code runs HERE instead of being refused:
+// one workgroup of 256 threads per frame, soft values / check records / edge signs in a per-workgroup slice of a workspace in
+// HBM (it is re-read every iteration, so it lives in L2 / Infinity Cache for the usual sizes), workgroup barriers between the
+// phases.  The grid is capped and strides over the frames, so the workspace does not grow with the batch.
+//
+//   tasp_global_kernel tdmp_sum_prod_gf2_decod_qc_lm  decoders.cpp:2584-2744 (decoder 7, the decoder of upstream's shipped scenarios):
+//                      per-edge lambda / rho / forward / backward products in the workspace instead of VGPRs, so row weight and
+//                      the number of circulants are unbounded (the resident tasp_body holds <= 144 edges in registers).
+// The arithmetic is upstream's, literally (comparisons `< 0`, explicit branches, additions in upstream's order):
+//   ms_global_kernel   min_sum_decod_qc_lm   decoders.cpp:4554-4767.  STATE1 is done from the VARIABLE side (a thread walks its
+//                      column's circulants in ascending block row = upstream's order of additions into soft[], :4633-4667), which
+//                      needs no atomics and no zeroing pass; STATE3 from the check side.
+//   lms_global_kernel  lmin_sum_decod_qc_lm  decoders.cpp:5064-5425 (MY_VERSION branch): layers strictly in sequence, inside a
+//                      layer every variable belongs to exactly one check.
+// Bit-identical hard decisions, return values and soft values (tests/test_gpu_shapes.py: against the CPU oracle on shapes the
+// resident kernels refuse, and against the golden vectors of the compiled reference with the tier forced on).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ldpc_kernels.hpp"
+#include "ldpc_spec.hpp"   // exp_glibc
+
+namespace ldpc {
+
+constexpr int kGlobThreads = 256;
+
+struct GlobArgs {
+    DecArgs d;          // tables: row_start, edges, col_start, col_edges, col_slot
+    char *ws;           // gridDim.x slices of ws_stride bytes
+    size_t ws_stride;
+    int ne;             // circulants
+};
+
+// slice layout (all offsets 16-byte aligned)
+struct GlobView {
+    double *soft, *m1, *m2, *tmp;   // tmp: `edge_arrays` arrays of ne * M doubles, one after the other
+    int32_t *pos;
+    uint8_t *par, *sgn;
+};
+__host__ __device__ inline size_t glob_align(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t glob_ws_bytes(int N, int R, int ne, int M, int edge_arrays) {
+    return glob_align(sizeof(double) * (size_t)N) + 2 * glob_align(sizeof(double) * (size_t)R) + glob_align(sizeof(int32_t) * (size_t)R) +
+           glob_align((size_t)R) + glob_align((size_t)ne * M) + (size_t)edge_arrays * glob_align(sizeof(double) * (size_t)ne * M);
+}
+__device__ inline GlobView glob_view(char *p, int N, int R, int ne, int M, int edge_arrays) {
+    GlobView v;
+    v.soft = reinterpret_cast<double *>(p); p += glob_align(sizeof(double) * (size_t)N);
+    v.m1 = reinterpret_cast<double *>(p); p += glob_align(sizeof(double) * (size_t)R);
+    v.m2 = reinterpret_cast<double *>(p); p += glob_align(sizeof(double) * (size_t)R);
+    v.pos = reinterpret_cast<int32_t *>(p); p += glob_align(sizeof(int32_t) * (size_t)R);
+    v.par = reinterpret_cast<uint8_t *>(p); p += glob_align((size_t)R);
+    v.sgn = reinterpret_cast<uint8_t *>(p); p += glob_align((size_t)ne * M);
+    v.tmp = edge_arrays ? reinterpret_cast<double *>(p) : nullptr;
+    return v;
+}
+
+template <bool PROB = false>   // PROB: probability-domain decoder, decword = soft > 0.5 (:2734); else soft < 0
+__device__ inline void glob_outputs(const DecArgs &a, const GlobView &w, long long fr, int res) {
+    const int N = a.N;
+    if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
+    if (a.hard) {
+        for (int wd = threadIdx.x; wd < a.hard_words; wd += kGlobThreads) {
+            uint32_t bits = 0;
+            for (int b = 0; b < 32; ++b) {
+                const int v = 32 * wd + b;
+                if (v < N) bits |= (uint32_t)(PROB ? w.soft[v] > 0.5 : w.soft[v] < 0) << b;      // decword[k] = soft[k] < 0  (:4683, :5418)
+            }
+            a.hard[fr * a.hard_words + wd] = bits;
+        }
+    }
+    if (a.soft_out)
+        for (int v = threadIdx.x; v < N; v += kGlobThreads) a.soft_out[fr * N + v] = w.soft[v];
+}
+
+__global__ void __launch_bounds__(kGlobThreads) ms_global_kernel(const GlobArgs g) {
+    const DecArgs &a = g.d;
+    const int M = a.M, N = a.N, R = a.rh * M, ne = g.ne;
+    const double alpha = a.alpha;
+    const GlobView w = glob_view(g.ws + (size_t)blockIdx.x * g.ws_stride, N, R, ne, M, 0);
+    for (long long fr = blockIdx.x; fr < a.B; fr += gridDim.x) {
+        const double *y = a.llr + fr * N;
+        for (int c = threadIdx.x; c < R; c += kGlobThreads) { w.m1[c] = 0.0; w.m2[c] = 0.0; w.pos[c] = 0; w.par[c] = 0; }   // :4579-4596
+        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += kGlobThreads) w.sgn[i] = 0;
+        __syncthreads();
+        int res = -a.maxiter;
+        for (int iter = 0; iter < a.maxiter; ++iter) {
+            // ---- STATE1 + STATE2 from the variable side (:4633-4685)
+            for (int v = threadIdx.x; v < N; v += kGlobThreads) {
+                const int k = v / M, i = v - k * M;
+                double acc = 0.0;                                                 // memset(soft, 0) :4630
+                for (int q = a.col_start[k]; q < a.col_start[k + 1]; ++q) {       // block rows ascending
+                    const uint32_t d = a.col_edges[q];
+                    const int j = (int)(d >> 16), c = (int)(d & 0xffffu), e = (int)a.col_slot[q];
+                    int n = i - c;                                                // check n of row j sees variable (k, (n + c) mod M)
+                    if (n < 0) n += M;
+                    const int chk = j * M + n;
+                    const double tmp = w.pos[chk] == e - a.row_start[j] ? w.m2[chk] : w.m1[chk];
+                    const double cv = (w.sgn[(size_t)e * M + n] ^ w.par[chk]) ? -tmp : tmp;
+                    acc = acc + cv;                                               // :4660
+                }
+                w.soft[v] = y[v] + acc * alpha;                                   // :4674 / :4682, two roundings
+            }
+            __syncthreads();
+            // ---- STATE3 from the check side (:4690-4755)
+            int fail = 0;
+            for (int chk = threadIdx.x; chk < R; chk += kGlobThreads) {
+                const int j = chk / M, n = chk - j * M;
+                const int e0 = a.row_start[j], e1 = a.row_start[j + 1];
+                const int po = w.pos[chk];
+                const uint8_t pa = w.par[chk];
+                const double o1 = w.m1[chk], o2 = w.m2[chk];
+                double nm1 = kMaxVal, nm2 = kMaxVal;
+                int np = 0, synd = 0;
+                uint8_t npar = 0;
+                for (int e = e0; e < e1; ++e) {
+                    const uint32_t d = a.edges[e];
+                    const int k = (int)(d >> 16), c = (int)(d & 0xffffu);
+                    int i = n + c;
+                    if (i >= M) i -= M;
+                    const double r = w.soft[k * M + i];
+                    synd ^= (int)(r < 0);                                         // :4712
+                    double val = (po == e - e0 ? o2 : o1) * alpha;               // :4720
+                    double t = (w.sgn[(size_t)e * M + n] ^ pa) ? -val : val;
+                    t = r - t;
+                    const uint8_t sign = t < 0;
+                    w.sgn[(size_t)e * M + n] = sign;
+                    npar ^= sign;
+                    val = t < 0.0 ? -t : t;
+                    val = (val > kMaxVal) ? kMaxVal : val;                        // :4730
+                    if (val < nm1) { np = e - e0; nm2 = nm1; nm1 = val; }
+                    else if (val < nm2) nm2 = val;
+                }
+                w.m1[chk] = nm1; w.m2[chk] = nm2; w.pos[chk] = np; w.par[chk] = npar;
+                fail |= synd;
+            }
+            if (!__syncthreads_or(fail)) { res = iter + 1; break; }               // :4757-4766 (the barrier also fences the next STATE1)
+        }
+        glob_outputs(a, w, fr, res);
+        __syncthreads();                                                          // the slice is reused by this workgroup's next frame
+    }
+}
+
+__global__ void __launch_bounds__(kGlobThreads) lms_global_kernel(const GlobArgs g) {
+    const DecArgs &a = g.d;
+    const int M = a.M, N = a.N, R = a.rh * M, ne = g.ne;
+    const GlobView w = glob_view(g.ws + (size_t)blockIdx.x * g.ws_stride, N, R, ne, M, 1);
+    auto syndrome = [&]() -> int {                                                // check_syndrome, decoders.cpp:793-814
+        int fail = 0;
+        for (int chk = threadIdx.x; chk < R; chk += kGlobThreads) {
+            const int j = chk / M, n = chk - j * M;
+            int synd = 0;
+            for (int e = a.row_start[j]; e < a.row_start[j + 1]; ++e) {
+                const uint32_t d = a.edges[e];
+                int i = n + (int)(d & 0xffffu);
+                if (i >= M) i -= M;
+                synd ^= (int)(w.soft[(int)(d >> 16) * M + i] < 0);
+            }
+            fail |= synd;
+        }
+        return __syncthreads_or(fail);
+    };
+    for (long long fr = blockIdx.x; fr < a.B; fr += gridDim.x) {
+        const double *y = a.llr + fr * N;
+        for (int v = threadIdx.x; v < N; v += kGlobThreads) w.soft[v] = y[v];    // :5088
+        for (int c = threadIdx.x; c < R; c += kGlobThreads) { w.m1[c] = 0.0; w.m2[c] = 0.0; w.pos[c] = 0; w.par[c] = 0; }
+        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += kGlobThreads) w.sgn[i] = 0;
+        __syncthreads();
+        int parity = syndrome();                                                   // :5111-5115
+        int iter = 0;
+        for (; iter < a.maxiter; ++iter) {
+            if (parity == 0) break;                                                // :5119
+            for (int j = 0; j < a.rh; ++j) {                                       // layers in sequence
+                const int e0 = a.row_start[j], e1 = a.row_start[j + 1];
+                for (int n = threadIdx.x; n < M; n += kGlobThreads) {
+                    const int chk = j * M + n;
+                    const int po = w.pos[chk];
+                    const uint8_t pa = w.par[chk];
+                    const double o1 = w.m1[chk], o2 = w.m2[chk];
+                    double nm1 = kMaxVal, nm2 = kMaxVal;                           // :5133-5134
+                    int np = 0;
+                    uint8_t npar = 0;
+                    for (int e = e0; e < e1; ++e) {                                // :5141-5177
+                        const uint32_t d = a.edges[e];
+                        int i = n + (int)(d & 0xffffu);
+                        if (i >= M) i -= M;
+                        const double prev_abs = po == e - e0 ? o2 : o1;
+                        const double prev_val = (w.sgn[(size_t)e * M + n] ^ pa) ? -prev_abs : prev_abs;
+                        const double t = w.soft[(int)(d >> 16) * M + i] - prev_val;
+                        const uint8_t sign = t < 0;
+                        double mag = t < 0.0 ? -t : t;
+                        mag -= 0.4;                                                 // beta :5163
+                        mag = mag < 0 ? 0 : mag;
+                        w.tmp[(size_t)e * M + n] = t;
+                        w.sgn[(size_t)e * M + n] = sign;
+                        npar ^= sign;                                              // process_check_node :5009-5027
+                        if (mag < nm1) { np = e - e0; nm2 = nm1; nm1 = mag; }
+                        else if (mag < nm2) nm2 = mag;
+                    }
+                    w.m1[chk] = nm1; w.m2[chk] = nm2; w.pos[chk] = np; w.par[chk] = npar;
+                    for (int e = e0; e < e1; ++e) {                                // :5182-5206
+                        const uint32_t d = a.edges[e];
+                        int i = n + (int)(d & 0xffffu);
+                        if (i >= M) i -= M;
+                        const double c_abs = np == e - e0 ? nm2 : nm1;
+                        const double c_val = (w.sgn[(size_t)e * M + n] ^ npar) ? -c_abs : c_abs;
+                        w.soft[(int)(d >> 16) * M + i] = w.tmp[(size_t)e * M + n] + c_val;
+                    }
+                }
+                __syncthreads();
+            }
+            parity = syndrome();                                                   // :5281-5288
+            if (parity == 0) break;
+        }
+        glob_outputs(a, w, fr, parity ? -iter : iter + 1);                         // :5424
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kGlobThreads) tasp_global_kernel(const GlobArgs g) {
+    const DecArgs &a = g.d;
+    const int M = a.M, N = a.N, R = a.rh * M, ne = g.ne;
+    const double T = 0.0001, TT = 0;                                                // :2597-2598
+    const GlobView w = glob_view(g.ws + (size_t)blockIdx.x * g.ws_stride, N, R, ne, M, 4);
+    const size_t EM = glob_align(sizeof(double) * (size_t)ne * M) / sizeof(double);
+    double *const Z = w.tmp, *const Y = w.tmp + EM, *const SF = w.tmp + 2 * EM, *const SB = w.tmp + 3 * EM;   // [e * M + k]
+    auto syndrome = [&]() -> int {                                                  // check_syndrome_thr :2274-2306, thr 0.5
+        int fail = 0;
+        for (int chk = threadIdx.x; chk < R; chk += kGlobThreads) {
+            const int j = chk / M, n = chk - j * M;
+            int synd = 0;
+            for (int e = a.row_start[j]; e < a.row_start[j + 1]; ++e) {
+                const uint32_t d = a.edges[e];
+                int i = n + (int)(d & 0xffffu);
+                if (i >= M) i -= M;
+                synd ^= (int)(w.soft[(int)(d >> 16) * M + i] > 0.5);
+            }
+            fail |= synd;
+        }
+        return __syncthreads_or(fail);
+    };
+    for (long long fr = blockIdx.x; fr < a.B; fr += gridDim.x) {
+        for (int v = threadIdx.x; v < N; v += kGlobThreads) {                       // :2611-2618
+            const double x = a.llr[fr * N + v] * 0.5;
+            const double y = x < 20.0 ? (x < -20.0 ? -20.0 : x) : 20.0;             // maxd(mind(x, INPUT_LIMIT), -INPUT_LIMIT)
+            const double e0 = ldpc_spec::exp_glibc(y), e1 = ldpc_spec::exp_glibc(-y);
+            w.soft[v] = e1 / (e0 + e1);
+        }
+        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += kGlobThreads) Z[i] = 0.5;   // :2637
+        __syncthreads();
+        int synd = syndrome();                                                      // :2653-2660
+        int steps = 0;
+        if (synd != 0) {
+            while (steps < a.maxiter) {
+                for (int j = 0; j < a.rh; ++j) {                                    // layers in sequence (:2668)
+                    const int e0 = a.row_start[j], e1 = a.row_start[j + 1], rw = e1 - e0;
+                    for (int k = threadIdx.x; k < M; k += kGlobThreads) {
+                        for (int e = e0; e < e1; ++e) {                             // :2676-2697
+                            const uint32_t d = a.edges[e];
+                            int i = k + (int)(d & 0xffffu);
+                            if (i >= M) i -= M;
+                            const double x = w.soft[(int)(d >> 16) * M + i];
+                            const double aa = Z[(size_t)e * M + k];
+                            double v = x * (1.0 - aa) / (aa + x - 2.0 * aa * x);    // rho = gamma - lambda
+                            if (v < TT) v = TT;
+                            if (v > 1 - TT) v = 1 - TT;
+                            Y[(size_t)e * M + k] = v;
+                        }
+                        // map_bin(a, cnt, 1) :2191-2228 with P[i] = 1 - 2 * y[i]
+                        auto P = [&](int i) { return 1 - 2 * Y[(size_t)(e0 + i) * M + k]; };
+                        auto sf = [&](int i) -> double & { return SF[(size_t)(e0 + i) * M + k]; };
+                        auto sb = [&](int i) -> double & { return SB[(size_t)(e0 + i) * M + k]; };
+                        sf(0) = P(0);
+                        for (int i = 1; i < rw - 1; ++i) sf(i) = P(i) * sf(i - 1);
+                        sb(rw - 1) = P(rw - 1);
+                        for (int i = rw - 2; i > 0; --i) sb(i) = P(i) * sb(i + 1);
+                        for (int i = 0; i < rw; ++i) {
+                            double q;
+                            if (i == 0) q = (1 - sb(1)) / 2;
+                            else if (i == rw - 1) q = (1 - sf(rw - 2)) / 2;
+                            else q = (1 - sf(i - 1) * sb(i + 1)) / 2;
+                            if (q < T) q = T;                                        // :2703-2704
+                            if (q > 1.0 - T) q = 1.0 - T;
+                            Z[(size_t)(e0 + i) * M + k] = q;
+                        }
+                        for (int e = e0; e < e1; ++e) {                             // :2707-2720
+                            const uint32_t d = a.edges[e];
+                            int i = k + (int)(d & 0xffffu);
+                            if (i >= M) i -= M;
+                            const double y = Y[(size_t)e * M + k], q = Z[(size_t)e * M + k];
+                            w.soft[(int)(d >> 16) * M + i] = y * q / (1.0 - y - q + 2 * y * q);   // gamma = rho + lambda
+                        }
+                    }
+                    __syncthreads();
+                }
+                synd = syndrome();                                                  // :2723 (the value after the last layer)
+                steps = steps + 1;
+                if (synd == 0) break;
+            }
+        }
+        glob_outputs<true>(a, w, fr, synd ? -steps : steps);                        // :2734-2743 (0 when the input was a codeword)
+        __syncthreads();
+    }
+}
+
+}  // namespace ldpc

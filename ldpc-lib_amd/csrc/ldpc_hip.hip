@@ -20,6 +20,7 @@
 #include "ldpc_frontend.hpp"
 #include "ldpc_jit.hpp"
 #include "ldpc_kernels.hpp"
+#include "ldpc_global.hpp"
 #include "ldpc_ms_fast.hpp"
 #include "ldpc_spec.hpp"
 #include "code_appendix_c_m64.hpp"
@@ -180,6 +181,11 @@ struct ldpc_hip_ctx {
     size_t lds_bytes = 0;
     double ims_thr = 1.4;  // MS_THR, MS_QBITS, MS_DBITS (decoders.h:46-48), see ldpc_hip_set_ims_params
     int ims_qbits = 6, ims_dbits = 8;
+    // shape-unlimited tier (ldpc_global.hpp): message state in a workspace in global memory
+    bool global_tier = false;
+    char *d_glob_ws = nullptr;
+    size_t glob_stride = 0;
+    int glob_grid = 0;
     // table-driven M = 64 min-sum kernel (ldpc_ms_fast.hpp)
     bool fast_m64 = false;
     int variant = 2;  // LDPC_HIP_MS_VARIANT: 2 code-specialised (AOT / hiprtc) [default], 0 table kernel with LDS fp64 atomics,
@@ -307,7 +313,8 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
     case LDPC_HIP_BP_DEC: {
         p.required = true;  // code-specialised instances only
         const size_t lds = ((((sizeof(double) + 1) * ((size_t)t.ne * M + (size_t)t.rh * M) + (size_t)N) + 15) & ~(size_t)15) + 16;
-        if (lds <= 160 * 1024) { p.body = "bp_body"; p.threads = 512; p.lds = lds; }
+        const size_t with_tables = lds + (size_t)ldpc_spec::kBpTabWords * 8;   // exp / log tables in LDS when they fit (bp_body: TAB_LDS)
+        if (lds <= 160 * 1024) { p.body = "bp_body"; p.threads = 512; p.lds = with_tables <= 160 * 1024 ? with_tables : lds; }
         break;
     }
     case LDPC_HIP_ASP_DEC: {
@@ -347,7 +354,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
     if (decoder_id != LDPC_HIP_MS_DEC && decoder_id != LDPC_HIP_LMS_DEC && decoder_id != LDPC_HIP_SP_DEC && decoder_id != LDPC_HIP_IMS_DEC &&
         decoder_id != LDPC_HIP_TASP_DEC && decoder_id != LDPC_HIP_ASP_DEC && decoder_id != LDPC_HIP_BP_DEC)
         return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_open: decoder id %d is not built (built: BP=0, SP=1, ASP=2, MS=3, IMS=4, TASP=7, LMS=8)", decoder_id);
-    if (M >= 65536 || nh >= 65536) return fail(LDPC_HIP_EUNSUPPORTED, "M and nh must be < 65536");
+    if (M >= 65536 || nh >= 65536 || rh >= 65536) return fail(LDPC_HIP_EUNSUPPORTED, "M, rh and nh must be < 65536");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(LDPC_HIP_EINVAL, "ldpc_hip_open: device %d of %d", device, ndev);
@@ -418,10 +425,19 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
             why_not = "LDPC_HIP_JIT=0";
         }
     }
-    if (!c->spec_aot && !c->spec_jit) {
+    const char *genv = getenv("LDPC_HIP_FORCE_GLOBAL");   // tests: run the shape-unlimited tier on shapes the resident kernels take
+    const bool can_global = decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || (decoder_id == LDPC_HIP_TASP_DEC && t.min_rw >= 2);
+    if (can_global && ((genv && atoi(genv) != 0) || (!c->spec_aot && !c->spec_jit && !have_generic))) {
+        c->global_tier = true;
+        c->spec_aot = nullptr; c->spec_jit = nullptr;
+        c->kernel_name = decoder_id == LDPC_HIP_MS_DEC ? "ms_global_kernel" : decoder_id == LDPC_HIP_LMS_DEC ? "lms_global_kernel" : "tasp_global_kernel";
+        c->glob_stride = ldpc::glob_ws_bytes(c->N, c->R, t.ne, M, decoder_id == LDPC_HIP_MS_DEC ? 0 : decoder_id == LDPC_HIP_LMS_DEC ? 1 : 4);
+    }
+    if (!c->spec_aot && !c->spec_jit && !c->global_tier) {
         if (!have_generic)
             return fail(LDPC_HIP_EUNSUPPORTED, "decoder %d, code %dx%d lifting %d: not supported by the generic kernel (limits: %d block rows, "
-                        "%d block columns, row weight %d, M <= 512, 160 KiB LDS) and no code-specialised instance: %s",
+                        "%d block columns, row weight %d, M <= 512, 160 KiB LDS), no code-specialised instance: %s; the shape-unlimited "
+                        "tier serves min-sum (3), layered min-sum (8) and TDMP sum-product (7) only",
                         decoder_id, rh, nh, M, kRHM, kNHM, kRWM, why_not.c_str());
         if (plan.body && c->variant >= 2)
             fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", why_not.c_str(), c->kernel_name.c_str());
@@ -460,6 +476,7 @@ void ldpc_hip_close(ldpc_hip_ctx *c) {
     if (c->d_bp_stale) (void)hipFree(c->d_bp_stale);
     if (c->d_bp_synd) (void)hipFree(c->d_bp_synd);
     if (c->d_bp_idx) (void)hipFree(c->d_bp_idx);
+    if (c->d_glob_ws) (void)hipFree(c->d_glob_ws);
     if (c->d_tx) (void)hipFree(c->d_tx);
     if (c->d_cw_packed) (void)hipFree(c->d_cw_packed);
     if (c->d_scatter) (void)hipFree(c->d_scatter);
@@ -500,8 +517,28 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
                         c->ims_dbits, alpha);
         use_spec = false;   // values beyond int8: table-driven int32 kernel
     }
-    c->last_launch = use_spec ? c->kernel_name.c_str() : c->generic_name.c_str();
-    if (use_spec) {
+    c->last_launch = (use_spec || c->global_tier) ? c->kernel_name.c_str() : c->generic_name.c_str();
+    if (c->global_tier) {
+        // one workgroup per frame, capped: the workspace is per workgroup and does not grow with the batch
+        int grid = (int)(B < 1024 ? B : 1024);
+        while (grid > 16 && (size_t)grid * c->glob_stride > ((size_t)8 << 30)) grid /= 2;
+        if (grid > c->glob_grid) {
+            if (c->d_glob_ws) (void)hipFree(c->d_glob_ws);
+            c->d_glob_ws = nullptr; c->glob_grid = 0;
+            HIP_TRY(hipMalloc(&c->d_glob_ws, (size_t)grid * c->glob_stride));
+            c->glob_grid = grid;
+        }
+        ldpc::GlobArgs ga{};
+        ga.d.llr = d_llr; ga.d.hard = d_hard; ga.d.iters = d_iters; ga.d.soft_out = d_soft;
+        ga.d.row_start = c->d_row_start; ga.d.edges = c->d_edges; ga.d.col_start = c->d_col_start; ga.d.col_edges = c->d_col_edges;
+        ga.d.col_slot = c->d_col_slot; ga.d.edge_row = c->d_edge_row;
+        ga.d.B = B; ga.d.rh = c->rh; ga.d.nh = c->nh; ga.d.M = c->M; ga.d.N = c->N; ga.d.F = 1; ga.d.maxiter = maxiter;
+        ga.d.hard_words = c->hard_words; ga.d.alpha = alpha;
+        ga.ws = c->d_glob_ws; ga.ws_stride = c->glob_stride; ga.ne = c->ne;
+        if (c->decoder_id == LDPC_HIP_MS_DEC) hipLaunchKernelGGL(ldpc::ms_global_kernel, dim3((unsigned)grid), dim3(ldpc::kGlobThreads), 0, stream, ga);
+        else if (c->decoder_id == LDPC_HIP_LMS_DEC) hipLaunchKernelGGL(ldpc::lms_global_kernel, dim3((unsigned)grid), dim3(ldpc::kGlobThreads), 0, stream, ga);
+        else hipLaunchKernelGGL(ldpc::tasp_global_kernel, dim3((unsigned)grid), dim3(ldpc::kGlobThreads), 0, stream, ga);
+    } else if (use_spec) {
         // code-specialised kernel: one frame per workgroup
         ldpc_spec::SpecArgs sa{};
         if (c->decoder_id == LDPC_HIP_IMS_DEC) {
@@ -697,6 +734,7 @@ static int prepare_chain(ldpc_hip_ctx *c, int modulation_type) {
     const int N = c->N, halfmlog = modulation_type <= 1 ? 1 : modulation_type;   // bp_simulation.cpp:402-411
     const int m = modulation_type <= 1 ? 2 : 2 * modulation_type;
     const int ntx = modulation_type <= 1 ? N : ((N + m - 1) / m) * m;           // extra_bits of :575, zero
+    if (c->d_glob_ws) (void)hipFree(c->d_glob_ws);
     if (c->d_tx) (void)hipFree(c->d_tx);
     if (c->d_cw_packed) (void)hipFree(c->d_cw_packed);
     if (c->d_scatter) (void)hipFree(c->d_scatter);

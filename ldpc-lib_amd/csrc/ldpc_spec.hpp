@@ -185,7 +185,8 @@ __device__ const unsigned long long kExpTab[256] = {
     0x3c8a64a931d185eeull, 0x3fefd0765b6e4540ull, 0xbc8e37bae43be3edull, 0x3fefdbfdad9cbe14ull,
     0x3c77893b4d91cd9dull, 0x3fefe7c1819e90d8ull, 0x3c5305c14160cc89ull, 0x3feff3c22b8f71f1ull
 };
-__device__ __forceinline__ double exp_glibc(double x) {
+template <class Tab>
+__device__ __forceinline__ double exp_glibc_t(double x, Tab T) {
     const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p52, NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
     const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
     const double z = InvLn2N * x;
@@ -194,13 +195,143 @@ __device__ __forceinline__ double exp_glibc(double x) {
     kd -= Shift;
     const double r = __fma_rn(kd, NegLn2loN, __fma_rn(kd, NegLn2hiN, x));   // x - k ln2/N
     const unsigned long long idx = 2 * (ki % 128);
-    const double tail = __longlong_as_double((long long)kExpTab[idx]);
-    const unsigned long long sbits = kExpTab[idx + 1] + (ki << (52 - 7));
+    const double tail = __longlong_as_double((long long)T[idx]);
+    const unsigned long long sbits = T[idx + 1] + (ki << (52 - 7));
     const double r2 = r * r;
     const double tmp = __fma_rn(r2 * r2, __fma_rn(r, C5, C4), __fma_rn(r2, __fma_rn(r, C3, C2), tail + r));
     const double scale = __longlong_as_double((long long)sbits);
     return __fma_rn(scale, tmp, scale);
 }
+__device__ __forceinline__ double exp_glibc(double x) { return exp_glibc_t(x, kExpTab); }
+
+// log() as the reference computes it (Gallager BP, decoder 0, is the one decoder with log inside its iteration): glibc >= 2.28's
+// algorithm (sysdeps/ieee754/dbl-64/e_log.c = ARM optimized-routines log, N = 128, polynomial orders 6 and 12) in the evaluation
+// order of the FMA build x86-64 hosts with FMA select at run time -- read off that build's instruction sequence.  kLogData is
+// printed by tools/gen_log_table.py: [0] ln2hi [1] ln2lo [2..6] A [7..17] B [18 + 2i] invc_i [19 + 2i] logc_i.
+// tests/test_host_cpu.py checks a C transcription against libm's log() bit for bit, all special cases included.
+__device__ const unsigned long long kLogData[274] = {
+    0x3fe62e42fefa3800ull, 0x3d2ef35793c76730ull, 0xbfe0000000000001ull, 0x3fd555555551305bull,
+    0xbfcfffffffeb4590ull, 0x3fc999b324f10111ull, 0xbfc55575e506c89full, 0xbfe0000000000000ull,
+    0x3fd5555555555577ull, 0xbfcffffffffffdcbull, 0x3fc999999995dd0cull, 0xbfc55555556745a7ull,
+    0x3fc24924a344de30ull, 0xbfbfffffa4423d65ull, 0x3fbc7184282ad6caull, 0xbfb999eb43b068ffull,
+    0x3fb78182f7afd085ull, 0xbfb5521375d145cdull, 0x3ff734f0c3e0de9full, 0xbfd7cc7f79e69000ull,
+    0x3ff713786a2ce91full, 0xbfd76feec20d0000ull, 0x3ff6f26008fab5a0ull, 0xbfd713e31351e000ull,
+    0x3ff6d1a61f138c7dull, 0xbfd6b85b38287800ull, 0x3ff6b1490bc5b4d1ull, 0xbfd65d5590807800ull,
+    0x3ff69147332f0cbaull, 0xbfd602d076180000ull, 0x3ff6719f18224223ull, 0xbfd5a8ca86909000ull,
+    0x3ff6524f99a51ed9ull, 0xbfd54f4356035000ull, 0x3ff63356aa8f24c4ull, 0xbfd4f637c36b4000ull,
+    0x3ff614b36b9ddc14ull, 0xbfd49da7fda85000ull, 0x3ff5f66452c65c4cull, 0xbfd445923989a800ull,
+    0x3ff5d867b5912c4full, 0xbfd3edf439b0b800ull, 0x3ff5babccb5b90deull, 0xbfd396ce448f7000ull,
+    0x3ff59d61f2d91a78ull, 0xbfd3401e17bda000ull, 0x3ff5805612465687ull, 0xbfd2e9e2ef468000ull,
+    0x3ff56397cee76bd3ull, 0xbfd2941b3830e000ull, 0x3ff54725e2a77f93ull, 0xbfd23ec58cda8800ull,
+    0x3ff52aff42064583ull, 0xbfd1e9e129279000ull, 0x3ff50f22dbb2bddfull, 0xbfd1956d2b48f800ull,
+    0x3ff4f38f4734ded7ull, 0xbfd141679ab9f800ull, 0x3ff4d843cfde2840ull, 0xbfd0edd094ef9800ull,
+    0x3ff4bd3ec078a3c8ull, 0xbfd09aa518db1000ull, 0x3ff4a27fc3e0258aull, 0xbfd047e65263b800ull,
+    0x3ff4880524d48434ull, 0xbfcfeb224586f000ull, 0x3ff46dce1b192d0bull, 0xbfcf474a7517b000ull,
+    0x3ff453d9d3391854ull, 0xbfcea4443d103000ull, 0x3ff43a2744b4845aull, 0xbfce020d44e9b000ull,
+    0x3ff420b54115f8fbull, 0xbfcd60a22977f000ull, 0x3ff40782da3ef4b1ull, 0xbfccc00104959000ull,
+    0x3ff3ee8f5d57fe8full, 0xbfcc202956891000ull, 0x3ff3d5d9a00b4ce9ull, 0xbfcb81178d811000ull,
+    0x3ff3bd60c010c12bull, 0xbfcae2c9ccd3d000ull, 0x3ff3a5242b75dab8ull, 0xbfca45402e129000ull,
+    0x3ff38d22cd9fd002ull, 0xbfc9a877681df000ull, 0x3ff3755bc5847a1cull, 0xbfc90c6d69483000ull,
+    0x3ff35dce49ad36e2ull, 0xbfc87120a645c000ull, 0x3ff34679984dd440ull, 0xbfc7d68fb4143000ull,
+    0x3ff32f5cceffcb24ull, 0xbfc73cb83c627000ull, 0x3ff3187775a10d49ull, 0xbfc6a39a9b376000ull,
+    0x3ff301c8373e3990ull, 0xbfc60b3154b7a000ull, 0x3ff2eb4ebb95f841ull, 0xbfc5737d76243000ull,
+    0x3ff2d50a0219a9d1ull, 0xbfc4dc7b8fc23000ull, 0x3ff2bef9a8b7fd2aull, 0xbfc4462c51d20000ull,
+    0x3ff2a91c7a0c1babull, 0xbfc3b08abc830000ull, 0x3ff293726014b530ull, 0xbfc31b996b490000ull,
+    0x3ff27dfa5757a1f5ull, 0xbfc2875490a44000ull, 0x3ff268b39b1d3bbfull, 0xbfc1f3b9f879a000ull,
+    0x3ff2539d838ff5bdull, 0xbfc160c8252ca000ull, 0x3ff23eb7aac9083bull, 0xbfc0ce7f57f72000ull,
+    0x3ff22a012ba940b6ull, 0xbfc03cdc49fea000ull, 0x3ff2157996cc4132ull, 0xbfbf57bdbc4b8000ull,
+    0x3ff201201dd2fc9bull, 0xbfbe370896404000ull, 0x3ff1ecf4494d480bull, 0xbfbd17983ef94000ull,
+    0x3ff1d8f5528f6569ull, 0xbfbbf9674ed8a000ull, 0x3ff1c52311577e7cull, 0xbfbadc79202f6000ull,
+    0x3ff1b17c74cb26e9ull, 0xbfb9c0c3e7288000ull, 0x3ff19e010c2c1ab6ull, 0xbfb8a646b372c000ull,
+    0x3ff18ab07bb670bdull, 0xbfb78d01b3ac0000ull, 0x3ff1778a25efbcb6ull, 0xbfb674f145380000ull,
+    0x3ff1648d354c31daull, 0xbfb55e0e6d878000ull, 0x3ff151b990275fddull, 0xbfb4485cdea1e000ull,
+    0x3ff13f0ea432d24cull, 0xbfb333d94d6aa000ull, 0x3ff12c8b7210f9daull, 0xbfb22079f8c56000ull,
+    0x3ff11a3028ecb531ull, 0xbfb10e4698622000ull, 0x3ff107fbda8434afull, 0xbfaffa6c6ad20000ull,
+    0x3ff0f5ee0f4e6bb3ull, 0xbfadda8d4a774000ull, 0x3ff0e4065d2a9fceull, 0xbfabbcece4850000ull,
+    0x3ff0d244632ca521ull, 0xbfa9a1894012c000ull, 0x3ff0c0a77ce2981aull, 0xbfa788583302c000ull,
+    0x3ff0af2f83c636d1ull, 0xbfa5715e67d68000ull, 0x3ff09ddb98a01339ull, 0xbfa35c8a49658000ull,
+    0x3ff08cabaf52e7dfull, 0xbfa149e364154000ull, 0x3ff07b9f2f4e28fbull, 0xbf9e72c082eb8000ull,
+    0x3ff06ab58c358f19ull, 0xbf9a55f152528000ull, 0x3ff059eea5ecf92cull, 0xbf963d62cf818000ull,
+    0x3ff04949cdd12c90ull, 0xbf9228fb8caa0000ull, 0x3ff038c6c6f0ada9ull, 0xbf8c317b20f90000ull,
+    0x3ff02865137932a9ull, 0xbf8419355daa0000ull, 0x3ff0182427ea7348ull, 0xbf781203c2ec0000ull,
+    0x3ff008040614b195ull, 0xbf60040979240000ull, 0x3fefe01ff726fa1aull, 0x3f6feff384900000ull,
+    0x3fefa11cc261ea74ull, 0x3f87dc41353d0000ull, 0x3fef6310b081992eull, 0x3f93cea3c4c28000ull,
+    0x3fef25f63ceeadcdull, 0x3f9b9fc114890000ull, 0x3feee9c8039113e7ull, 0x3fa1b0d8ce110000ull,
+    0x3feeae8078cbb1abull, 0x3fa58a5bd001c000ull, 0x3fee741aa29d0c9bull, 0x3fa95c8340d88000ull,
+    0x3fee3a91830a99b5ull, 0x3fad276aef578000ull, 0x3fee01e009609a56ull, 0x3fb07598e598c000ull,
+    0x3fedca01e577bb98ull, 0x3fb253f5e30d2000ull, 0x3fed92f20b7c9103ull, 0x3fb42edd8b380000ull,
+    0x3fed5cac66fb5cceull, 0x3fb606598757c000ull, 0x3fed272caa5ede9dull, 0x3fb7da76356a0000ull,
+    0x3fecf26e3e6b2ccdull, 0x3fb9ab434e1c6000ull, 0x3fecbe6da2a77902ull, 0x3fbb78c7bb0d6000ull,
+    0x3fec8b266d37086dull, 0x3fbd431332e72000ull, 0x3fec5894bd5d5804ull, 0x3fbf0a3171de6000ull,
+    0x3fec26b533bb9f8cull, 0x3fc067152b914000ull, 0x3febf583eeece73full, 0x3fc147858292b000ull,
+    0x3febc4fd75db96c1ull, 0x3fc2266ecdca3000ull, 0x3feb951e0c864a28ull, 0x3fc303d7a6c55000ull,
+    0x3feb65e2c5ef3e2cull, 0x3fc3dfc33c331000ull, 0x3feb374867c9888bull, 0x3fc4ba366b7a8000ull,
+    0x3feb094b211d304aull, 0x3fc5933928d1f000ull, 0x3feadbe885f2ef7eull, 0x3fc66acd2418f000ull,
+    0x3feaaf1d31603da2ull, 0x3fc740f8ec669000ull, 0x3fea82e63fd358a7ull, 0x3fc815c0f51af000ull,
+    0x3fea5740ef09738bull, 0x3fc8e92954f68000ull, 0x3fea2c2a90ab4b27ull, 0x3fc9bb3602f84000ull,
+    0x3fea01a01393f2d1ull, 0x3fca8bed1c2c0000ull, 0x3fe9d79f24db3c1bull, 0x3fcb5b515c01d000ull,
+    0x3fe9ae2505c7b190ull, 0x3fcc2967ccbcc000ull, 0x3fe9852ef297ce2full, 0x3fccf635d5486000ull,
+    0x3fe95cbaeea44b75ull, 0x3fcdc1bd3446c000ull, 0x3fe934c69de74838ull, 0x3fce8c01b8cfe000ull,
+    0x3fe90d4f2f6752e6ull, 0x3fcf5509c0179000ull, 0x3fe8e6528effd79dull, 0x3fd00e6c121fb800ull,
+    0x3fe8bfce9fcc007cull, 0x3fd071b80e93d000ull, 0x3fe899c0dabec30eull, 0x3fd0d46b9e867000ull,
+    0x3fe87427aa2317fbull, 0x3fd13687334bd000ull, 0x3fe84f00acb39a08ull, 0x3fd1980d67234800ull,
+    0x3fe82a49e8653e55ull, 0x3fd1f8ffe0cc8000ull, 0x3fe8060195f40260ull, 0x3fd2595fd7636800ull,
+    0x3fe7e22563e0a329ull, 0x3fd2b9300914a800ull, 0x3fe7beb377dcb5adull, 0x3fd3187210436000ull,
+    0x3fe79baa679725c2ull, 0x3fd377266dec1800ull, 0x3fe77907f2170657ull, 0x3fd3d54ffbaf3000ull,
+    0x3fe756cadbd6130cull, 0x3fd432eee32fe000ull
+};
+template <class Tab>
+__device__ __forceinline__ double log_glibc_t(double x, Tab T) {
+    auto D = [&](int i) { return __longlong_as_double((long long)T[i]); };
+    unsigned long long ix = (unsigned long long)__double_as_longlong(x);
+    const u32 top = (u32)(ix >> 48);
+    const unsigned long long LO = 0x3fee000000000000ull /* 1.0 - 0x1p-4 */, HI = 0x3ff1090000000000ull /* 1.0 + 0x1.09p-4 */;
+    if (ix - LO < HI - LO) {                                          // close to 1.0
+        if (ix == 0x3ff0000000000000ull) return 0.0;
+        const double r = x - 1.0, r2 = r * r, r3 = r * r2;
+        const double t3 = __fma_rn(r3, D(17), __fma_rn(r2, D(16), __fma_rn(r, D(15), D(14))));
+        const double t2 = __fma_rn(r3, t3, __fma_rn(r2, D(13), __fma_rn(r, D(12), D(11))));
+        const double t1 = __fma_rn(r3, t2, __fma_rn(r2, D(10), __fma_rn(r, D(9), D(8))));
+        double w = r * 0x1p27;
+        const double rhi = r + w - w, rlo = r - rhi;
+        w = rhi * rhi * D(7);                                         // B[0] == -0.5
+        const double hi = r + w;
+        double lo = r - hi + w;
+        lo = __fma_rn(D(7) * rlo, rhi + r, lo);
+        return __fma_rn(t1, r3, lo) + hi;
+    }
+    if (top - 0x0010u >= 0x7ff0u - 0x0010u) {                          // x < 0x1p-1022, inf or nan
+        if (ix * 2 == 0) return -__longlong_as_double(0x7ff0000000000000ll);   // log(+-0) = -inf
+        if (ix == 0x7ff0000000000000ull) return x;                     // log(inf) = inf
+        if ((top & 0x8000u) || (top & 0x7ff0u) == 0x7ff0u) return __longlong_as_double(0x7ff8000000000000ll) ;   // x < 0 or NaN: NaN (payload irrelevant here)
+        ix = (unsigned long long)__double_as_longlong(x * 0x1p52);     // subnormal: normalise
+        ix -= 52ull << 52;
+    }
+    const unsigned long long tmp = ix - 0x3fe6000000000000ull;         // x = 2^k z, z in [OFF, 2 OFF)
+    const int i = (int)((tmp >> (52 - 7)) % 128);
+    const long long k = (long long)tmp >> 52;
+    const unsigned long long iz = ix - (tmp & (0xfffull << 52));
+    const double invc = D(18 + 2 * i), logc = D(19 + 2 * i), z = __longlong_as_double((long long)iz);
+    const double r = __fma_rn(z, invc, -1.0);
+    const double kd = (double)k;
+    const double w = __fma_rn(kd, D(0), logc);
+    const double hi = w + r;
+    const double lo = __fma_rn(kd, D(1), w - hi + r);
+    const double r2 = r * r;
+    const double p = __fma_rn(r, D(6), D(5));
+    const double q = __fma_rn(r2, p, __fma_rn(r, D(4), D(3)));
+    return __fma_rn(r * r2, q, __fma_rn(r2, D(2), lo)) + hi;
+}
+__device__ __forceinline__ double log_glibc(double x) { return log_glibc_t(x, kLogData); }
+// exp() for arguments that may leave exp_glibc's range: glibc takes a separate path for |x| >= 512 (overflow / underflow handling);
+// there the result is +inf / 0 or deep in the subnormal range, where ocml's exp agrees on the values that matter (inf, 0).  The BP
+// decoder's arguments stay far below 512 unless a message was exactly 0 or 1 in the probability sense (log(0) = -inf).
+template <class Tab>
+__device__ __forceinline__ double exp_glibc_wide(double x, Tab T) {
+    return fabs(x) < 512.0 ? exp_glibc_t(x, T) : exp(x);
+}
+constexpr int kBpTabWords = 256 + 274;   // kExpTab + kLogData: bp_body keeps a copy in LDS when the code leaves room (divergent table
+                                         // look-ups from global memory cost the kernel a quarter of its speed)
 
 // Upstream clamps with mind()/maxd() (decoders.cpp:104-105: a < b ? a : b and a < b ? b : a) or with `if (v < lo) v = lo`.
 // For a value that is not NaN and ordinary constant bounds v_min_f64 / v_max_f64 return the same double in ONE instruction;
@@ -1545,8 +1676,8 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
 // Upstream does not clear its syndrome array before the input check (:1742-1762), so that check sees the syndrome the
 // previous call on the same state left behind (non-zero after a failed frame): `stale` carries
 // it in, `synd_out` carries it out, and the host chains frames in order (ldpc_hip.hip).
-// exp()/log() are ocml's: hard decisions and iteration counts identical to the reference on all test sets (and
-// insensitive to +-1 ulp perturbations of every exp/log, tests/test_oracle_golden.py), soft values to tolerance.
+// exp() / log() are evaluated with glibc's own algorithms (exp_glibc, log_glibc above), so the a-posteriori LLRs equal the CPU
+// reference's bit for bit like everything else (round 1 used ocml's and matched to rtol 1e-5).
 // ---------------------------------------------------------------------------------------------------------------
 template <class C>
 __device__ __forceinline__ void bp_body(const SpecArgs &a) {
@@ -1561,6 +1692,13 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
     unsigned char *const hb = bsb + R;                                                // [N] soft < 0
     constexpr size_t kFlagOff = (((size_t)(NE * M + R) * 9 + N) + 15) & ~(size_t)15;  // 16-byte aligned behind the byte arrays
     int *const flag = reinterpret_cast<int *>(zzb + kFlagOff);
+    constexpr bool TAB_LDS = kFlagOff + 16 + (size_t)kBpTabWords * 8 <= (size_t)160 * 1024;   // same rule as the host (plan_spec)
+    const unsigned long long *etab = kExpTab, *ltab = kLogData;
+    if constexpr (TAB_LDS) {
+        unsigned long long *t = reinterpret_cast<unsigned long long *>(zzb + kFlagOff + 16);
+        for (int i = threadIdx.x; i < kBpTabWords; i += T) t[i] = i < 256 ? kExpTab[i] : kLogData[i - 256];   // visible after the barrier below
+        etab = t; ltab = t + 256;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // lanes beyond the lifting in the last 64-lane chunk of a circulant sit out
@@ -1619,8 +1757,8 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
                 static_for<0, V.cw[k]>([&](auto X) {
                     constexpr int e = V.ce[k][decltype(X)::value];
                     double *z = reinterpret_cast<double *>(zzb + (size_t)e * M * 8 + t * 8);
-                    const double A = exp(so[q] - *z);
-                    *z = log(fabs((A - 1) / (A + 1)));
+                    const double A = exp_glibc_wide(so[q] - *z, etab);
+                    *z = log_glibc_t(fabs((A - 1) / (A + 1)), ltab);
                     bbb[e * M + t] = A < 1;
                 });
             }
@@ -1654,9 +1792,9 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
                     constexpr int x = decltype(X)::value, e = V.ce[k][x], j = V.cj[k][x];
                     int nn = t - V.cc[k][x]; if (nn < 0) nn += M;                     // rotate by m - circ (:1847)
                     double *z = reinterpret_cast<double *>(zzb + (size_t)e * M * 8 + t * 8);
-                    double A = exp(*reinterpret_cast<const double *>(sb + (size_t)(j * M + nn) * 8) - *z);
+                    double A = exp_glibc_wide(*reinterpret_cast<const double *>(sb + (size_t)(j * M + nn) * 8) - *z, etab);
                     const int b = bsb[j * M + nn] ^ bbb[e * M + t];
-                    A = (double)(1 - 2 * b) * log((1 + A) / (1 - A));
+                    A = (double)(1 - 2 * b) * log_glibc_t((1 + A) / (1 - A), ltab);
                     const double zn = at_least(at_most(A, 19.07), -19.07);
                     *z = zn;
                     soft += zn;

@@ -1,0 +1,140 @@
+"""GPU: code shapes.  (a) shapes of upstream's own scenario files that the resident kernels must take without scratch surprises
+(30 x 60 at lifting 67, files/input12L.jsonx:3-6; row weight 16); (b) shapes beyond the LDS-resident kernels' limits, which run on
+the shape-unlimited tier (ldpc_global.hpp) instead of being refused -- upstream's decod_open has no such limits
+(decoders.cpp:348-791); (c) that tier forced onto the golden vectors of the compiled reference.  Everything bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from ldpc_testlib import (GOLDEN_DIR, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Oracle, awgn_llr, load_base_matrix, pack_bits, random_qc_code,
+                          relift)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import ldpc_lib_amd
+    return ldpc_lib_amd
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _check(L, torch, dec_id, H, M, llr, maxiter, expect_kernel=None, soft=True):
+    o = Oracle(H, M)
+    with L.LdpcHip(dec_id, H, M) as dec:
+        if expect_kernel:
+            assert expect_kernel in dec.kernel_name, dec.kernel_name
+        hard, iters, sv = dec.decode(torch.from_numpy(llr).cuda(), maxiter, want_soft=soft)
+        torch.cuda.synchronize()
+        d_ref, it_ref, _ = o.decode(dec_id, llr, maxiter, 0)
+        assert np.array_equal(iters.cpu().numpy(), it_ref)
+        assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
+        if soft and dec_id != TASP_DEC:
+            s_ref, _, _ = o.decode(dec_id, llr, maxiter, 1)
+            assert np.array_equal(sv.cpu().numpy(), s_ref)
+        return dec.kernel_name, it_ref
+
+
+def _rows_of_weight(rng, rh, nh, M, target):
+    """Dual-diagonal parity part + information part in which every block row has exactly `target` circulants in total and every
+    information column at least one."""
+    H = random_qc_code(rng, rh, nh, M, [1])
+    H[:, rh:] = -1
+    ninfo = nh - rh
+    start = 0
+    for j in range(rh):
+        need = target - int((H[j] >= 0).sum())
+        assert 2 <= need <= ninfo
+        for q in range(need):                              # a rolling window: rows overlap, all columns get covered
+            H[j, rh + (start + q) % ninfo] = rng.randint(0, M)
+        start += need - 1
+    assert ((H >= 0).sum(axis=1) == target).all() and ((H[:, rh:] >= 0).sum(axis=0) >= 1).all()
+    return H
+
+
+def _llr(H, M, snr, seed, frames):
+    return awgn_llr(np.asarray(H, dtype=np.int32), M, snr, seed, frames, burn_codeword=False)
+
+
+@pytest.mark.parametrize("dec_id,maxiter,snr", [(MS_DEC, 50, 2.2), (LMS_DEC, 50, 1.4), (TASP_DEC, 15, 1.4)])
+def test_thirty_by_sixty_at_lifting_67(L, torch, dec_id, maxiter, snr):
+    """The shape of files/input12L.jsonx (rows 30, columns 60, tailbite length 67; information column weights 2 / 3 / 16).
+    Min-sum and layered min-sum run on hiprtc instances of the resident bodies; TDMP sum-product has 206 circulants, more than the
+    144 whose state tasp_body can hold in registers, and runs on the shape-unlimited tier."""
+    rng = np.random.RandomState(67)
+    H = random_qc_code(rng, 30, 60, 67, [2, 3, 3, 16, 2, 3])
+    llr = _llr(H, 67, snr, 5, 24)
+    name, it = _check(L, torch, dec_id, H, 67, llr, maxiter)
+    assert (it > 0).any() and (it < 0).any(), it       # both converged and failed frames in the sample
+
+
+@pytest.mark.parametrize("dec_id", [MS_DEC, LMS_DEC])
+def test_row_weight_sixteen(L, torch, dec_id):
+    H = _rows_of_weight(np.random.RandomState(16), 4, 24, 64, 16)
+    _check(L, torch, dec_id, H, 64, _llr(H, 64, 3.0, 7, 32), 30)
+
+
+GLOBAL_SHAPES = [
+    # what the resident kernels refuse                                   rh  nh   M    weights        snr
+    ("lifting 600 > 512",                                                 16, 32, 600, None,          1.6),
+    ("N * 8 B = 256 KiB > 160 KiB of LDS (lifting 1024)",                 16, 32, 1024, None,         1.6),
+    ("70 block rows > 64",                                                70, 140, 8,  [2, 3, 3, 4],  2.5),
+    ("row weight 20 > 16",                                                4, 28, 32,   [3],           4.0),
+    ("an empty block column",                                             6, 12, 64,   [2, 3],        3.0),
+]
+
+
+@pytest.mark.parametrize("dec_id", [MS_DEC, LMS_DEC, TASP_DEC])
+@pytest.mark.parametrize("why,rh,nh,M,weights,snr", GLOBAL_SHAPES)
+def test_shapes_beyond_the_resident_kernels_run_on_the_global_tier(L, torch, dec_id, why, rh, nh, M, weights, snr):
+    rng = np.random.RandomState(rh * 1000 + nh)
+    if weights is None:
+        H = relift(load_base_matrix(), M)
+    elif "row weight" in why:
+        H = _rows_of_weight(rng, rh, nh, M, 20)
+    else:
+        H = random_qc_code(rng, rh, nh, M, weights)
+    if "empty" in why:
+        H[:, nh - 1] = -1                               # an information column no check looks at: soft stays y
+        for j in range(rh):
+            while (H[j, rh:] >= 0).sum() < 2:
+                H[j, rh + rng.randint(0, nh - rh - 1)] = rng.randint(0, M)
+    frames = 6 if M >= 600 else 16
+    # (an empty column only rules out the code-specialised bodies: the table-driven kernels of min-sum / layered min-sum take it)
+    expect = None if ("empty" in why and dec_id != TASP_DEC) else "_global_kernel"
+    name, it = _check(L, torch, dec_id, H, M, _llr(H, M, snr, 3, frames), 15 if dec_id == TASP_DEC else 30, expect_kernel=expect)
+
+
+def test_decoders_without_a_global_tier_still_fail_loudly(L, torch):
+    H = relift(load_base_matrix(), 600)
+    with pytest.raises(L.LdpcHipError, match="shape-unlimited"):
+        L.LdpcHip(SP_DEC, H, 600)
+
+
+@pytest.mark.parametrize("name", ["ms_m64_1p2", "ms_m126_1p7", "ms_m1_4p0", "ms_m512_1p6", "lms_m64_0p8", "lms_m512_1p0", "lms_m1_4p0",
+                                  "tasp_m64_1p7", "tasp_m126_1p7", "tasp_m1_4p0"])
+def test_global_tier_on_the_compiled_references_vectors(L, torch, name, monkeypatch):
+    """LDPC_HIP_FORCE_GLOBAL=1: the tier takes shapes the resident kernels normally serve, so it can be pinned by the golden
+    vectors the compiled upstream code produced: hard bits, return values, soft values."""
+    monkeypatch.setenv("LDPC_HIP_FORCE_GLOBAL", "1")
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    H, M, dec_id, maxiter = g["H"], int(g["M"]), int(g["dec_id"]), int(g["maxiter"])
+    with L.LdpcHip(dec_id, H, M) as dec:
+        assert "_global_kernel" in dec.kernel_name
+        hard, iters, _ = dec.decode(torch.from_numpy(g["llr"]).cuda(), maxiter)
+        ns = g["soft"].shape[0]
+        _, it2, soft = dec.decode(torch.from_numpy(g["llr"][:ns]).cuda(), maxiter, want_soft=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(iters.cpu().numpy(), g["iters"]) and np.array_equal(it2.cpu().numpy(), g["iters"][:ns])
+        assert np.array_equal(hard.cpu().numpy().view(np.uint32), g["hard"])
+        if dec_id == TASP_DEC:   # upstream ignores `decision` here (decoders.cpp:2737-2738): the golden "soft" is the hard decision again
+            assert np.array_equal((soft.cpu().numpy() > 0.5).astype(np.float64), g["soft"])
+        else:
+            assert np.array_equal(soft.cpu().numpy(), g["soft"])

@@ -330,9 +330,10 @@ def test_device_exp_algorithm_equals_libm_exp_bit_for_bit(tmp_path):
     body = hdr[hdr.index("kExpTab[256] = {") + len("kExpTab[256] = {"):]
     body = body[:body.index("};")]
     assert [int(x.strip().rstrip("ull"), 16) for x in body.replace("\n", " ").split(",") if x.strip()] == tab
-    fn = hdr[hdr.index("__device__ __forceinline__ double exp_glibc(double x) {"):]
+    fn = hdr[hdr.index("__device__ __forceinline__ double exp_glibc_t(double x, Tab T) {"):]
     fn = fn[:fn.index("\n}\n") + 3]
-    c_fn = (fn.replace("__device__ __forceinline__ ", "static ").replace("__fma_rn", "fma")
+    c_fn = (fn.replace("__device__ __forceinline__ double exp_glibc_t(double x, Tab T)", "static double exp_glibc(double x)").replace("__fma_rn", "fma")
+              .replace("T[idx + 1]", "kExpTab[idx + 1]").replace("T[idx]", "kExpTab[idx]")
               .replace("(unsigned long long)__double_as_longlong(kd)", "asu(kd)")
               .replace("__longlong_as_double((long long)kExpTab[idx])", "asd(kExpTab[idx])")
               .replace("__longlong_as_double((long long)sbits)", "asd(sbits)"))
@@ -347,3 +348,44 @@ def test_device_exp_algorithm_equals_libm_exp_bit_for_bit(tmp_path):
     (tmp_path / "e.c").write_text(src)
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", str(tmp_path / "e.c"), "-o", str(tmp_path / "e"), "-lm"])
     assert subprocess.check_output([str(tmp_path / "e")], text=True).strip() == "0"
+
+
+def test_device_log_algorithm_equals_libm_log_bit_for_bit(tmp_path):
+    """ldpc_spec::log_glibc (Gallager BP's log) is glibc's log() algorithm with the data tools/gen_log_table.py reads from this
+    host's libm.  A C transcription of exactly the header's code -- same data, same fma placement -- must return libm's log() bit
+    for bit on this host (x86-64 with FMA: glibc's run-time selected FMA build): (0,1), (1,inf), the near-1 path, subnormals,
+    and the special values 0, 1, inf."""
+    import subprocess
+    if " fma" not in open("/proc/cpuinfo").read():
+        pytest.skip("host without FMA: glibc selects its non-FMA log build there")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_log_table
+    tab = gen_log_table.table()
+    hdr = open(os.path.join(ROOT, "ldpc-lib_amd", "csrc", "ldpc_spec.hpp")).read()
+    body = hdr[hdr.index("kLogData[274] = {") + len("kLogData[274] = {"):]
+    body = body[:body.index("};")]
+    assert [int(x.strip().rstrip("ull"), 16) for x in body.replace("\n", " ").split(",") if x.strip()] == tab
+    fn = hdr[hdr.index("__device__ __forceinline__ double log_glibc_t(double x, Tab T) {"):]
+    fn = fn[:fn.index("\n}\n") + 3]
+    c_fn = (fn.replace("__device__ __forceinline__ double log_glibc_t(double x, Tab T)", "static double log_glibc(double x)").replace("__fma_rn", "fma")
+              .replace("    auto D = [&](int i) { return __longlong_as_double((long long)T[i]); };\n", "")
+              .replace("(unsigned long long)__double_as_longlong(", "asu(").replace("__longlong_as_double((long long)iz)", "asd(iz)")
+              .replace("__longlong_as_double(0x7ff0000000000000ll)", "asd(0x7ff0000000000000ull)")
+              .replace("__longlong_as_double(0x7ff8000000000000ll)", "asd(0x7ff8000000000000ull)")
+              )
+    src = ("#include <math.h>\n#include <stdint.h>\n#include <stdio.h>\n#include <string.h>\n"
+           "static unsigned long long asu(double x){unsigned long long u;memcpy(&u,&x,8);return u;}\n"
+           "static double asd(unsigned long long u){double x;memcpy(&x,&u,8);return x;}\n"
+           "static const unsigned long long kLogData[274] = {" + ",".join("0x%xull" % v for v in tab) + "};\n"
+           "typedef unsigned u32;\n#define D(i) asd(kLogData[i])\n" + c_fn +
+           "int main(){unsigned long long s=88172645463325252ull;long bad=0,n=6000000;\n"
+           " double sp[5]={0.0,1.0,1.0/0.0,0x1p-1074,0x1.fffffffffffffp1023};\n"
+           " for(int i=0;i<5;i++) if(asu(log_glibc(sp[i]))!=asu(log(sp[i]))) bad++;\n"
+           " if(!isnan(log_glibc(-1.0))||!isnan(log_glibc(0.0/0.0))) bad++;\n"
+           " for(long i=0;i<n;i++){s^=s<<13;s^=s>>7;s^=s<<17;double u=((double)(s>>11)/9007199254740992.0),x;int m=i%4;\n"
+           "  if(m==0) x=u; else if(m==1) x=1.0/(u+1e-300); else if(m==2) x=0.9375+u*0.13; else x=ldexp(u,-(int)(s%1070));\n"
+           "  if(asu(log_glibc(x))!=asu(log(x))) bad++;}\n"
+           " printf(\"%ld\\n\",bad);return bad!=0;}\n")
+    (tmp_path / "l.c").write_text(src)
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", str(tmp_path / "l.c"), "-o", str(tmp_path / "l"), "-lm"])
+    assert subprocess.check_output([str(tmp_path / "l")], text=True).strip() == "0"
