@@ -1,4 +1,5 @@
-// ldpc_global.hpp -- the shape-unlimited tier: flooding min-sum and layered min-sum with the message state in GLOBAL memory.
+// ldpc_global.hpp -- the shape-unlimited tier: min-sum, layered min-sum, sum-product and TDMP sum-product with the message state in
+// GLOBAL memory.
 //
 // The LDS/VGPR-resident kernels (ldpc_spec.hpp, ldpc_kernels.hpp) need the a-posteriori values of a frame in one CU's LDS
 // (N * 8 B <= 160 KiB), M <= 512, <= 64 block rows / columns, row weight <= 16 and no empty block column.  Upstream's decod_open
@@ -7,6 +8,7 @@
 // HBM (it is re-read every iteration, so it lives in L2 / Infinity Cache for the usual sizes), workgroup barriers between the
 // phases.  The grid is capped and strides over the frames, so the workspace does not grow with the batch.
 //
+//   sp_global_kernel   sum_prod_decod_qc_lm  decoders.cpp:1923-2185: the four phases of ldpc_sumprod.hpp, arrays in the workspace.
 //   tasp_global_kernel tdmp_sum_prod_gf2_decod_qc_lm  decoders.cpp:2584-2744 (decoder 7, the decoder of upstream's shipped scenarios):
 //                      per-edge lambda / rho / forward / backward products in the workspace instead of VGPRs, so row weight and
 //                      the number of circulants are unbounded (the resident tasp_body holds <= 144 edges in registers).
@@ -39,18 +41,19 @@ struct GlobArgs {
 
 // slice layout (all offsets 16-byte aligned)
 struct GlobView {
-    double *soft, *m1, *m2, *tmp;   // tmp: `edge_arrays` arrays of ne * M doubles, one after the other
+    double *soft, *aux, *m1, *m2, *tmp;   // aux: [N]; tmp: `edge_arrays` arrays of ne * M doubles, one after the other
     int32_t *pos;
     uint8_t *par, *sgn;
 };
 __host__ __device__ inline size_t glob_align(size_t x) { return (x + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t glob_ws_bytes(int N, int R, int ne, int M, int edge_arrays) {
-    return glob_align(sizeof(double) * (size_t)N) + 2 * glob_align(sizeof(double) * (size_t)R) + glob_align(sizeof(int32_t) * (size_t)R) +
+    return 2 * glob_align(sizeof(double) * (size_t)N) + 2 * glob_align(sizeof(double) * (size_t)R) + glob_align(sizeof(int32_t) * (size_t)R) +
            glob_align((size_t)R) + glob_align((size_t)ne * M) + (size_t)edge_arrays * glob_align(sizeof(double) * (size_t)ne * M);
 }
 __device__ inline GlobView glob_view(char *p, int N, int R, int ne, int M, int edge_arrays) {
     GlobView v;
     v.soft = reinterpret_cast<double *>(p); p += glob_align(sizeof(double) * (size_t)N);
+    v.aux = reinterpret_cast<double *>(p); p += glob_align(sizeof(double) * (size_t)N);
     v.m1 = reinterpret_cast<double *>(p); p += glob_align(sizeof(double) * (size_t)R);
     v.m2 = reinterpret_cast<double *>(p); p += glob_align(sizeof(double) * (size_t)R);
     v.pos = reinterpret_cast<int32_t *>(p); p += glob_align(sizeof(int32_t) * (size_t)R);
@@ -60,7 +63,7 @@ __device__ inline GlobView glob_view(char *p, int N, int R, int ne, int M, int e
     return v;
 }
 
-template <bool PROB = false>   // PROB: probability-domain decoder, decword = soft > 0.5 (:2734); else soft < 0
+template <int KIND = 0>   // hard decision: 0 soft < 0 (LLR decoders), 1 soft > 0.5 (probability domain, :2734), 2 soft < 1.0 (likelihood ratios, :2172)
 __device__ inline void glob_outputs(const DecArgs &a, const GlobView &w, long long fr, int res) {
     const int N = a.N;
     if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
@@ -69,7 +72,7 @@ __device__ inline void glob_outputs(const DecArgs &a, const GlobView &w, long lo
             uint32_t bits = 0;
             for (int b = 0; b < 32; ++b) {
                 const int v = 32 * wd + b;
-                if (v < N) bits |= (uint32_t)(PROB ? w.soft[v] > 0.5 : w.soft[v] < 0) << b;      // decword[k] = soft[k] < 0  (:4683, :5418)
+                if (v < N) bits |= (uint32_t)(KIND == 1 ? w.soft[v] > 0.5 : KIND == 2 ? w.soft[v] < 1.0 : w.soft[v] < 0) << b;      // decword[k] = soft[k] < 0  (:4683, :5418)
             }
             a.hard[fr * a.hard_words + wd] = bits;
         }
@@ -303,7 +306,92 @@ __global__ void __launch_bounds__(kGlobThreads) tasp_global_kernel(const GlobArg
                 if (synd == 0) break;
             }
         }
-        glob_outputs<true>(a, w, fr, synd ? -steps : steps);                        // :2734-2743 (0 when the input was a codeword)
+        glob_outputs<1>(a, w, fr, synd ? -steps : steps);                        // :2734-2743 (0 when the input was a codeword)
+        __syncthreads();
+    }
+}
+
+// sum_prod_decod_qc_lm, decoders.cpp:1923-2185 (likelihood-ratio domain), the four phases of ldpc_sumprod.hpp with every array in
+// the workspace: ZZ[e][t] per edge and variable position, yd / soft per variable, the check products in m1[].
+__global__ void __launch_bounds__(kGlobThreads) sp_global_kernel(const GlobArgs g) {
+    const DecArgs &a = g.d;
+    const int M = a.M, N = a.N, R = a.rh * M, ne = g.ne;
+    const GlobView w = glob_view(g.ws + (size_t)blockIdx.x * g.ws_stride, N, R, ne, M, 1);
+    double *const ZZ = w.tmp, *const yd = w.aux, *const S = w.m1;
+    auto mind = [](double x, double y) { return x < y ? x : y; };   // decoders.cpp:104-105
+    auto maxd = [](double x, double y) { return x < y ? y : x; };
+    auto syndrome = [&]() -> int {                                                  // :1964-2002 / :2129-2149
+        int fail = 0;
+        for (int chk = threadIdx.x; chk < R; chk += kGlobThreads) {
+            const int j = chk / M, n = chk - j * M;
+            int synd = 0;
+            for (int e = a.row_start[j]; e < a.row_start[j + 1]; ++e) {
+                const uint32_t d = a.edges[e];
+                int i = n + (int)(d & 0xffffu);
+                if (i >= M) i -= M;
+                synd ^= (int)(w.soft[(int)(d >> 16) * M + i] < 1.0);
+            }
+            fail |= synd;
+        }
+        return __syncthreads_or(fail);
+    };
+    for (long long fr = blockIdx.x; fr < a.B; fr += gridDim.x) {
+        for (int v = threadIdx.x; v < N; v += kGlobThreads) {                       // :1947-1951
+            const double yl = maxd(mind(a.llr[fr * N + v], 20.0), -20.0);
+            yd[v] = w.soft[v] = ldpc_spec::exp_glibc(yl);
+        }
+        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += kGlobThreads) ZZ[i] = 1.0;   // :1957-1959
+        __syncthreads();
+        int res = -a.maxiter;
+        bool conv = syndrome() == 0;
+        if (conv) res = 0;
+        for (int iter = 0; !conv && iter < a.maxiter; ++iter) {
+            for (int v = threadIdx.x; v < N; v += kGlobThreads) {                   // phase A :2017-2060
+                const int k = v / M, t = v - k * M;
+                const int c0 = a.col_start[k], c1 = a.col_start[k + 1];
+                double prefix = yd[v];
+                for (int u = c0; u < c1; ++u) {
+                    const size_t zi = (size_t)a.col_slot[u] * M + t;
+                    const double orig = ZZ[zi];
+                    double AA = prefix;
+                    for (int x = u + 1; x < c1; ++x) AA *= ZZ[(size_t)a.col_slot[x] * M + t];
+                    ZZ[zi] = (AA - 1) / (AA + 1);
+                    prefix *= orig;
+                }
+            }
+            __syncthreads();
+            for (int chk = threadIdx.x; chk < R; chk += kGlobThreads) {             // phase B :2047-2050
+                const int j = chk / M, n = chk - j * M;
+                double s = 1.0;
+                for (int e = a.row_start[j]; e < a.row_start[j + 1]; ++e) {
+                    int i = n + (int)(a.edges[e] & 0xffffu);
+                    if (i >= M) i -= M;
+                    s *= ZZ[(size_t)e * M + i];
+                }
+                S[chk] = s;
+            }
+            __syncthreads();
+            for (int v = threadIdx.x; v < N; v += kGlobThreads) {                   // phase C :2103-2127
+                const int k = v / M, t = v - k * M;
+                double soft = yd[v];
+                for (int u = a.col_start[k]; u < a.col_start[k + 1]; ++u) {
+                    const uint32_t d = a.col_edges[u];
+                    const int j = (int)(d >> 16), c = (int)(d & 0xffffu);
+                    int nn = t - c;
+                    if (nn < 0) nn += M;
+                    const size_t zi = (size_t)a.col_slot[u] * M + t;
+                    double A = S[j * M + nn] / ZZ[zi];
+                    A = (1 + A) / (1 - A);
+                    A = maxd(mind(A, 1.9e+8), -5.2e-9);                             // :2120 (the negative lower clamp is upstream's)
+                    ZZ[zi] = A;
+                    soft *= A;
+                }
+                w.soft[v] = soft;
+            }
+            __syncthreads();
+            if (syndrome() == 0) { conv = true; res = iter + 1; }                   // :2151-2166
+        }
+        glob_outputs<2>(a, w, fr, res);
         __syncthreads();
     }
 }

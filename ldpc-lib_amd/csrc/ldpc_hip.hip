@@ -426,18 +426,20 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
         }
     }
     const char *genv = getenv("LDPC_HIP_FORCE_GLOBAL");   // tests: run the shape-unlimited tier on shapes the resident kernels take
-    const bool can_global = decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || (decoder_id == LDPC_HIP_TASP_DEC && t.min_rw >= 2);
+    const bool can_global = decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || decoder_id == LDPC_HIP_SP_DEC ||
+                            (decoder_id == LDPC_HIP_TASP_DEC && t.min_rw >= 2);
     if (can_global && ((genv && atoi(genv) != 0) || (!c->spec_aot && !c->spec_jit && !have_generic))) {
         c->global_tier = true;
         c->spec_aot = nullptr; c->spec_jit = nullptr;
-        c->kernel_name = decoder_id == LDPC_HIP_MS_DEC ? "ms_global_kernel" : decoder_id == LDPC_HIP_LMS_DEC ? "lms_global_kernel" : "tasp_global_kernel";
-        c->glob_stride = ldpc::glob_ws_bytes(c->N, c->R, t.ne, M, decoder_id == LDPC_HIP_MS_DEC ? 0 : decoder_id == LDPC_HIP_LMS_DEC ? 1 : 4);
+        c->kernel_name = decoder_id == LDPC_HIP_MS_DEC ? "ms_global_kernel" : decoder_id == LDPC_HIP_LMS_DEC ? "lms_global_kernel" :
+                         decoder_id == LDPC_HIP_SP_DEC ? "sp_global_kernel" : "tasp_global_kernel";
+        c->glob_stride = ldpc::glob_ws_bytes(c->N, c->R, t.ne, M, decoder_id == LDPC_HIP_MS_DEC ? 0 : decoder_id == LDPC_HIP_TASP_DEC ? 4 : 1);
     }
     if (!c->spec_aot && !c->spec_jit && !c->global_tier) {
         if (!have_generic)
             return fail(LDPC_HIP_EUNSUPPORTED, "decoder %d, code %dx%d lifting %d: not supported by the generic kernel (limits: %d block rows, "
                         "%d block columns, row weight %d, M <= 512, 160 KiB LDS), no code-specialised instance: %s; the shape-unlimited "
-                        "tier serves min-sum (3), layered min-sum (8) and TDMP sum-product (7) only",
+                        "tier serves sum-product (1), min-sum (3), TDMP sum-product (7) and layered min-sum (8) only",
                         decoder_id, rh, nh, M, kRHM, kNHM, kRWM, why_not.c_str());
         if (plan.body && c->variant >= 2)
             fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", why_not.c_str(), c->kernel_name.c_str());
@@ -537,6 +539,7 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
         ga.ws = c->d_glob_ws; ga.ws_stride = c->glob_stride; ga.ne = c->ne;
         if (c->decoder_id == LDPC_HIP_MS_DEC) hipLaunchKernelGGL(ldpc::ms_global_kernel, dim3((unsigned)grid), dim3(ldpc::kGlobThreads), 0, stream, ga);
         else if (c->decoder_id == LDPC_HIP_LMS_DEC) hipLaunchKernelGGL(ldpc::lms_global_kernel, dim3((unsigned)grid), dim3(ldpc::kGlobThreads), 0, stream, ga);
+        else if (c->decoder_id == LDPC_HIP_SP_DEC) hipLaunchKernelGGL(ldpc::sp_global_kernel, dim3((unsigned)grid), dim3(ldpc::kGlobThreads), 0, stream, ga);
         else hipLaunchKernelGGL(ldpc::tasp_global_kernel, dim3((unsigned)grid), dim3(ldpc::kGlobThreads), 0, stream, ga);
     } else if (use_spec) {
         // code-specialised kernel: one frame per workgroup

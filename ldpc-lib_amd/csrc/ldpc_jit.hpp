@@ -8,6 +8,7 @@
 #pragma once
 
 #include <dlfcn.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <hip/hip_runtime.h>
 
@@ -128,10 +129,20 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
     const std::string src = "#include \"ldpc_spec.hpp\"\nnamespace {\n" + code +
                             "}\nextern \"C\" __global__ void __launch_bounds__(" + std::to_string(threads) + (eight_waves ? ", 4" : (std::string(body) == "tasp_body" || std::string(body) == "ms_chunk_body") ? ", 1" : ", 2") + ") spec_jit(const ldpc_spec::SpecArgs a) {\n"
                             "    ldpc_spec::" + body + "<Code>(a);\n}\n";
-    // Optional on-disk cache of compiled code objects (LDPC_HIP_CACHE_DIR; off by default): the file name is a hash of
-    // everything the object depends on -- the generated source, this header's text and the target.
+    // On-disk cache of compiled code objects: LDPC_HIP_CACHE_DIR, default $XDG_CACHE_HOME/ldpc_hip or $HOME/.cache/ldpc_hip,
+    // "off" disables it.  The file name is a hash of everything the object depends on -- the generated source, this header's
+    // text and the target -- so a stale entry cannot be picked up; a later process loads the object in milliseconds instead of
+    // compiling for seconds.
     std::string cache_file;
-    if (const char *dir = getenv("LDPC_HIP_CACHE_DIR")) {
+    std::string cache_dir;
+    if (const char *dir = getenv("LDPC_HIP_CACHE_DIR")) cache_dir = dir;
+    else if (const char *x = getenv("XDG_CACHE_HOME")) cache_dir = std::string(x) + "/ldpc_hip";
+    else if (const char *h = getenv("HOME")) cache_dir = std::string(h) + "/.cache/ldpc_hip";
+    if (cache_dir == "off" || cache_dir == "0") cache_dir.clear();
+    if (!cache_dir.empty()) {
+        for (size_t i = 1; i <= cache_dir.size(); ++i)     // mkdir -p, best effort
+            if (i == cache_dir.size() || cache_dir[i] == '/') (void)mkdir(cache_dir.substr(0, i).c_str(), 0755);
+        const char *dir = cache_dir.c_str();
         unsigned long long h = 1469598103934665603ull;   // FNV-1a 64
         auto mix = [&](const std::string &t) { for (unsigned char ch : t) { h ^= ch; h *= 1099511628211ull; } };
         mix(src); mix(hdr); mix("gfx950 -O3 -ffp-contract=off");

@@ -365,7 +365,7 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
     const double *const yrow = a.llr + fr * N + lane;  // this frame's channel LLRs, variable (k, lane) at yrow[64 k]
 
     double m1[RH], m2[RH];
-    u32 meta[RH];  // [15:0] v2c sign bits, slot s of a row of weight RW on bit RW-1-s; [23:16] slot of the min1 edge
+    u32 meta[RH];  // [31:32-RW] sign of the c2v on slot s (own v2c sign xor row parity) on bit 31-s, ready to use; [7:0] slot of the min1 edge
     static_for<0, RH>([&](auto J) {
         constexpr int j = decltype(J)::value;
         m1[j] = 0.0; m2[j] = 0.0; meta[j] = 0u;   // :4579-4596
@@ -391,10 +391,10 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
             // depends on its outputs: the row's ALU work therefore stays between the previous row's LDS operations
             // and its own (otherwise instruction selection emits all 112 c2v computations first and spills them).
             asm volatile("" : "+v"(mt), "+v"(nb));
-            const u32 pos = mt >> 16;
+            const u32 pos = mt & 0xffu;
             // sign of the c2v on slot s = (own v2c sign) xor (row sign); slot s sits on bit RW-1-s of the row word.
             // Wt carries slot 0 on bit 31; every further slot is one full-rate add (Wt += Wt) instead of a shift.
-            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - C::RW[j]);
+            u32 Wt = mt;   // the record keeps the sign word ready: slot s on bit 31 - s, row parity folded in
             static_for<0, C::RW[j]>([&](auto S) {
                 constexpr int s = decltype(S)::value;
                 constexpr int k = C::COL[j][s];
@@ -424,8 +424,8 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
             // opaque: otherwise the compiler keeps STATE1's 112 select masks and shifted sign words alive across the
             // whole iteration to reuse them here (SGPR + VGPR spills to scratch); recomputing costs 3 ops per edge.
             asm volatile("" : "+v"(mt));
-            const u32 pos = mt >> 16;
-            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - RW);
+            const u32 pos = mt & 0xffu;
+            u32 Wt = mt;   // the record keeps the sign word ready: slot s on bit 31 - s, row parity folded in
             double a1 = m1[j] * alpha, a2 = m2[j] * alpha;
             asm volatile("" : "+v"(a1), "+v"(a2));  // two products per ROW, not one per edge
             double nm1 = kMaxVal, nm2 = kMaxVal;    // start value == the MAX_VAL clamp of :4730
@@ -452,7 +452,7 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
                 nm1 = fmin(v, nm1);
             });
             failw |= sy;
-            m1[j] = nm1; m2[j] = nm2; meta[j] = nS | (npos << 16);
+            m1[j] = nm1; m2[j] = nm2; meta[j] = ((nS ^ (0u - (__popc(nS) & 1u))) << (32 - RW)) | npos;
             __builtin_amdgcn_sched_barrier(0);
         });
         if (__ballot((failw >> 31) != 0) == 0ull) { res = iter + 1; break; }  // :4761-4766
@@ -526,8 +526,8 @@ __device__ __forceinline__ void ms_body(const SpecArgs &a) {
             constexpr int j = decltype(J)::value;
             u32 mt = meta[j], nb = n8;
             asm volatile("" : "+v"(mt), "+v"(nb) :: "memory");  // compiler fence: this row's work stays behind the previous barrier
-            const u32 pos = mt >> 16;
-            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - C::RW[j]);
+            const u32 pos = mt & 0xffu;
+            u32 Wt = mt;   // the record keeps the sign word ready: slot s on bit 31 - s, row parity folded in
             static_for<0, C::RW[j]>([&](auto S) {
                 constexpr int s = decltype(S)::value;
                 const double aa = sel64(m1[j], m2[j], lanes_eq(pos, (u32)s));
@@ -560,8 +560,8 @@ __device__ __forceinline__ void ms_body(const SpecArgs &a) {
             constexpr int RW = C::RW[j];
             u32 mt = meta[j];
             asm volatile("" : "+v"(mt) :: "memory");
-            const u32 pos = mt >> 16;
-            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - RW);
+            const u32 pos = mt & 0xffu;
+            u32 Wt = mt;   // the record keeps the sign word ready: slot s on bit 31 - s, row parity folded in
             double a1 = m1[j] * alpha, a2 = m2[j] * alpha;
             asm volatile("" : "+v"(a1), "+v"(a2));
             double nm1 = kMaxVal, nm2 = kMaxVal;
@@ -588,7 +588,7 @@ __device__ __forceinline__ void ms_body(const SpecArgs &a) {
                 nm1 = fmin(v, nm1);
             });
             failw |= sy;
-            m1[j] = nm1; m2[j] = nm2; meta[j] = nS | (npos << 16);
+            m1[j] = nm1; m2[j] = nm2; meta[j] = ((nS ^ (0u - (__popc(nS) & 1u))) << (32 - RW)) | npos;
             // materialise the new record HERE: it is only consumed by the next iteration, and without this the compiler
             // sinks all 112 min1/min2 updates below the convergence branch and keeps every v2c alive across the vote
             asm volatile("" : "+v"(m1[j]), "+v"(m2[j]), "+v"(meta[j]));
@@ -672,8 +672,8 @@ __device__ __forceinline__ void ms_small_body(const SpecArgs &a) {
             constexpr int j = decltype(J)::value;
             u32 mt = meta[j], nb = n8;
             asm volatile("" : "+v"(mt), "+v"(nb));
-            const u32 pos = mt >> 16;
-            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - C::RW[j]);
+            const u32 pos = mt & 0xffu;
+            u32 Wt = mt;   // the record keeps the sign word ready: slot s on bit 31 - s, row parity folded in
             static_for<0, C::RW[j]>([&](auto S) {
                 constexpr int s = decltype(S)::value;
                 const double aa = sel64(m1[j], m2[j], lanes_eq(pos, (u32)s));
@@ -704,8 +704,8 @@ __device__ __forceinline__ void ms_small_body(const SpecArgs &a) {
             constexpr int RW = C::RW[j];
             u32 mt = meta[j];
             asm volatile("" : "+v"(mt));
-            const u32 pos = mt >> 16;
-            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - RW);
+            const u32 pos = mt & 0xffu;
+            u32 Wt = mt;   // the record keeps the sign word ready: slot s on bit 31 - s, row parity folded in
             double a1 = m1[j] * alpha, a2 = m2[j] * alpha;
             asm volatile("" : "+v"(a1), "+v"(a2));
             double nm1 = kMaxVal, nm2 = kMaxVal;
@@ -732,7 +732,7 @@ __device__ __forceinline__ void ms_small_body(const SpecArgs &a) {
                 nm1 = fmin(v, nm1);
             });
             failw |= sy;
-            m1[j] = nm1; m2[j] = nm2; meta[j] = nS | (npos << 16);
+            m1[j] = nm1; m2[j] = nm2; meta[j] = ((nS ^ (0u - (__popc(nS) & 1u))) << (32 - RW)) | npos;
             asm volatile("" : "+v"(m1[j]), "+v"(m2[j]), "+v"(meta[j]));
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -813,8 +813,8 @@ __device__ __forceinline__ void ms_chunk_body(const SpecArgs &a) {
                 constexpr int ch = decltype(Q)::value;
                 u32 mt = meta[ch][j], nb = n8[ch];
                 asm volatile("" : "+v"(mt), "+v"(nb) :: "memory");
-                const u32 pos = mt >> 16;
-                u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - C::RW[j]);
+                const u32 pos = mt & 0xffu;
+                u32 Wt = mt;   // the record keeps the sign word ready: slot s on bit 31 - s, row parity folded in
                 static_for<0, C::RW[j]>([&](auto S) {
                     constexpr int s = decltype(S)::value;
                     const double aa = sel64(m1[ch][j], m2[ch][j], lanes_eq(pos, (u32)s));
@@ -868,8 +868,8 @@ __device__ __forceinline__ void ms_chunk_body(const SpecArgs &a) {
                 constexpr int ch = decltype(Q)::value;
                 u32 mt = meta[ch][j];
                 asm volatile("" : "+v"(mt));
-                const u32 pos = mt >> 16;
-                u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - RW);
+                const u32 pos = mt & 0xffu;
+                u32 Wt = mt;   // the record keeps the sign word ready: slot s on bit 31 - s, row parity folded in
                 double a1 = m1[ch][j] * alpha, a2 = m2[ch][j] * alpha;
                 asm volatile("" : "+v"(a1), "+v"(a2));
                 double nm1 = kMaxVal, nm2 = kMaxVal;
@@ -896,7 +896,7 @@ __device__ __forceinline__ void ms_chunk_body(const SpecArgs &a) {
                     nm1 = fmin(v, nm1);
                 });
                 failw |= ok[ch] ? sy : 0u;
-                m1[ch][j] = nm1; m2[ch][j] = nm2; meta[ch][j] = nS | (npos << 16);
+                m1[ch][j] = nm1; m2[ch][j] = nm2; meta[ch][j] = ((nS ^ (0u - (__popc(nS) & 1u))) << (32 - RW)) | npos;
                 asm volatile("" : "+v"(m1[ch][j]), "+v"(m2[ch][j]), "+v"(meta[ch][j]));
             });
             __builtin_amdgcn_sched_barrier(0);
@@ -1001,8 +1001,8 @@ __device__ __forceinline__ void lms_body(const SpecArgs &a) {
             constexpr int RW = C::RW[j];
             u32 mt = meta[j], nb = n8;
             asm volatile("" : "+v"(mt), "+v"(nb));         // anchor: keeps this layer's ALU work behind the barrier
-            const u32 pos = mt >> 16;
-            u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - RW);
+            const u32 pos = mt & 0xffu;
+            u32 Wt = mt;   // the record keeps the sign word ready: slot s on bit 31 - s, row parity folded in
             double nm1 = kMaxVal, nm2 = kMaxVal;           // :5133-5134 (no clamp of the v2c magnitudes in this decoder)
             u32 npos = 0, nS = 0;
             double r[RW], tv[RW];
@@ -1025,7 +1025,8 @@ __device__ __forceinline__ void lms_body(const SpecArgs &a) {
                 npos = sel32(npos, (u32)s, c1);
                 nm1 = fmin(mag, nm1);
             });
-            u32 Wn = (nS ^ (0u - (__popc(nS) & 1u))) << (32 - RW);
+            const u32 W0 = (nS ^ (0u - (__popc(nS) & 1u))) << (32 - RW);
+            u32 Wn = W0;
             static_for<0, RW>([&](auto S) {                // :5182-5206
                 constexpr int s = decltype(S)::value;
                 const double aa = sel64(nm1, nm2, lanes_eq(npos, (u32)s));
@@ -1033,7 +1034,7 @@ __device__ __forceinline__ void lms_body(const SpecArgs &a) {
                 Wn = twice(Wn);
                 if (valid) *reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M)) = tv[s] + cv;
             });
-            m1[j] = nm1; m2[j] = nm2; meta[j] = nS | (npos << 16);
+            m1[j] = nm1; m2[j] = nm2; meta[j] = W0 | npos;
             if constexpr (W > 1) __syncthreads();           // the next layer reads what this one wrote
             else __builtin_amdgcn_sched_barrier(0);
         });
@@ -1137,8 +1138,8 @@ __device__ __forceinline__ void lms_small_body(const SpecArgs &a) {
                 constexpr int RW = C::RW[j];
                 u32 mt = meta[j], nb = n8;
                 asm volatile("" : "+v"(mt), "+v"(nb));
-                const u32 pos = mt >> 16;
-                u32 Wt = ((mt & 0xffffu) ^ (0u - (__popc(mt & 0xffffu) & 1u))) << (32 - RW);
+                const u32 pos = mt & 0xffu;
+                u32 Wt = mt;   // the record keeps the sign word ready: slot s on bit 31 - s, row parity folded in
                 double nm1 = kMaxVal, nm2 = kMaxVal;       // :5133-5134
                 u32 npos = 0, nS = 0;
                 double r[RW], tv[RW];
@@ -1161,7 +1162,8 @@ __device__ __forceinline__ void lms_small_body(const SpecArgs &a) {
                     npos = sel32(npos, (u32)s, c1);
                     nm1 = fmin(mag, nm1);
                 });
-                u32 Wn = (nS ^ (0u - (__popc(nS) & 1u))) << (32 - RW);
+                const u32 W0 = (nS ^ (0u - (__popc(nS) & 1u))) << (32 - RW);
+            u32 Wn = W0;
                 static_for<0, RW>([&](auto S) {            // :5182-5206
                     constexpr int s = decltype(S)::value;
                     const double aa = sel64(nm1, nm2, lanes_eq(npos, (u32)s));
@@ -1169,7 +1171,7 @@ __device__ __forceinline__ void lms_small_body(const SpecArgs &a) {
                     Wn = twice(Wn);
                     *reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M)) = tv[s] + cv;
                 });
-                m1[j] = nm1; m2[j] = nm2; meta[j] = nS | (npos << 16);
+                m1[j] = nm1; m2[j] = nm2; meta[j] = W0 | npos;
                 asm volatile("" ::: "memory");             // the next layer reads what this one wrote (LDS runs a wave's accesses in order)
                 __builtin_amdgcn_sched_barrier(0);
             });
