@@ -1,0 +1,23 @@
+#!/bin/bash
+# The round's measurement pass on one MI355X: PMC passes for every bench configuration -> profiles/r02_pmc.json (keyed by the hash of
+# the kernel sources), bench.py plain -> r02_bench.json, bench.py under rocprofv3 --kernel-trace --stats -> kernel stats CSV.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/r02
+rm -rf gpurun_out/pmc2
+bash tools/prof_pmc2.sh > gpurun_out/r02/pmc2.log 2>&1 || { tail -20 gpurun_out/r02/pmc2.log; exit 1; }
+tail -7 gpurun_out/r02/pmc2.log
+cp gpurun_out/r02_pmc.json profiles/r02_pmc.json
+timeout -k 10 600 python bench.py > gpurun_out/r02/r02_bench.json 2> gpurun_out/r02/r02_bench.err || { tail -5 gpurun_out/r02/r02_bench.err; exit 1; }
+python3 - <<'PY'
+import json
+b=json.load(open("gpurun_out/r02/r02_bench.json"))
+print("value", b["value"], "ms/step", b["ms_per_step"])
+r=b["roofline"]; print("roofline eff frac", r["frac"], "valu", r["valu_issue"], "lds", r["lds"], "hbm", r["hbm_physical"])
+for k,c in b.get("configs",{}).items():
+    if "error" in c: print(k, c["error"]); continue
+    print(k, "worst %.3f M fr/s"%(c["worst_case"]["value"]/1e6), "oper %.3f M"%(c["operating_point"]["value"]/1e6), "kernel_ms", round(c["roofline"]["kernel_ms_avg"],3), "valu frac", (c["roofline"]["valu_issue"] or {}).get("frac"), "hbm frac", (c["roofline"]["hbm_physical"] or {}).get("frac"))
+print("cpu", b["cpu_baseline"])
+PY
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02/trace -- python3 bench.py --no-cpu-baseline > gpurun_out/r02/r02_bench_under_rocprof.json 2> gpurun_out/r02/trace.err || { tail -5 gpurun_out/r02/trace.err; exit 1; }
+find gpurun_out/r02/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r02/r02_kernel_stats.csv
+head -12 gpurun_out/r02/r02_kernel_stats.csv | cut -c1-160

@@ -18,20 +18,24 @@ from ldpc_testlib import ASP_DEC, BP_DEC, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, TASP
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 FAMILY = (SP_DEC, ASP_DEC, TASP_DEC, BP_DEC) if "--sp" in sys.argv else (MS_DEC, LMS_DEC, IMS_DEC)
+GLOBAL = "--global" in sys.argv     # the shape-unlimited tier (ldpc_global.hpp) forced on: no hiprtc, larger shapes too
+if GLOBAL:
+    os.environ["LDPC_HIP_FORCE_GLOBAL"] = "1"
+    FAMILY = (MS_DEC, LMS_DEC, SP_DEC, TASP_DEC)
 if "--only" in sys.argv:
-    FAMILY = (int(sys.argv[sys.argv.index("--only") + 1]),)   # --sp: sum-product family, soft values to tolerance
-TOL = {BP_DEC: (1e-5, 1e-7)}   # SP / ASP / TDMP: exp() is glibc's algorithm on the device -> soft values bit for bit
+    FAMILY = (int(sys.argv[sys.argv.index("--only") + 1]),)
+TOL = {}   # every decoder bit for bit: exp() / log() are glibc's algorithms on the device
 t0 = time.time()
 bad = 0
 for case in range(cases):
-    rh = int(rng.randint(2, 13))
-    nh = rh + int(rng.randint(2, 14))
-    M = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 21, 27, 32, 33, 40, 47, 48, 63, 64, 65, 67, 96, 100, 126, 128, 129, 160, 200, 256]))
+    rh = int(rng.randint(2, 40 if GLOBAL else 13))
+    nh = rh + int(rng.randint(2, 40 if GLOBAL else 14))
+    M = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 21, 27, 32, 33, 40, 47, 48, 63, 64, 65, 67, 96, 100, 126, 128, 129, 160, 200, 256] + ([300, 513, 700] if GLOBAL else [])))
     weights = tuple(int(x) for x in rng.randint(2, min(rh, 6) + 1, size=4))
     H = random_qc_code(rng, rh, nh, M, weights)
-    if (H >= 0).sum(axis=1).max() > 8:
+    if (H >= 0).sum(axis=1).max() > 8 and not GLOBAL:
         continue
-    frames = 24 if M * nh > 2000 else 70
+    frames = 8 if M * nh > 20000 else 24 if M * nh > 2000 else 70
     llr = np.concatenate([awgn_llr(H, M, s, 500 + case, frames // 2) for s in (2.0, 5.0)])
     if "--sp" not in sys.argv:
         llr[0, :3] = [0.0, -0.0, 40000.0]
