@@ -1859,6 +1859,9 @@ __device__ __forceinline__ int med3i(int x, int y, int z) {   // median of three
 #ifndef LDPC_IMS_MSG_COPIES
 #define LDPC_IMS_MSG_COPIES 1
 #endif
+#ifndef LDPC_IMS_PACK_IY
+#define LDPC_IMS_PACK_IY 1    // quantised channel values four to a VGPR (they are int8): 24 fewer live registers, no scratch spills at 3 waves per SIMD
+#endif
 
 template <class C>
 struct ColView {   // column view of the code, compile time
@@ -1914,7 +1917,9 @@ __device__ __forceinline__ void ims_body_t(const SpecArgs &a) {
         else return fvote(fail);
     };
 
-    int iy[NH];                                                             // :5472-5500 energy-normalised quantiser
+    constexpr bool PACK_IY = LDPC_IMS_PACK_IY != 0;
+    int iy[PACK_IY ? (NH + 3) / 4 : NH];                                    // :5472-5500 energy-normalised quantiser
+    if constexpr (PACK_IY) static_for<0, (NH + 3) / 4>([&](auto Q) { iy[decltype(Q)::value] = 0; });
     {
         const double coef = a.ims_coef[frv];
         const double *yrow = a.llr + frv * N + nv;
@@ -1926,9 +1931,19 @@ __device__ __forceinline__ void ims_body_t(const SpecArgs &a) {
             val *= coef;
             if (val > a.ims_thr) val = a.ims_thr;
             const int ival = (int)(short)floor(val * a.ims_max_quant / a.ims_thr + 0.5);
-            iy[k] = sign ? -ival : ival;
+            const int q = sign ? -ival : ival;                              // |q| <= max_quant <= 127: one byte
+            if constexpr (PACK_IY) iy[k >> 2] |= (q & 0xff) << (8 * (k & 3));
+            else iy[k] = q;
         });
     }
+    auto iy_of = [&](auto K) -> int {
+        constexpr int k = decltype(K)::value;
+        if constexpr (PACK_IY) {
+            int w = iy[k >> 2];
+            asm volatile("" : "+v"(w));     // opaque per use: otherwise the unpacking is hoisted out of the iteration loop and all NH values stay live
+            return __builtin_amdgcn_sbfe(w, 8 * (k & 3), 8);
+        } else return iy[k];
+    };
     u32 pm[RH][2];                                                          // the messages this check sent last (bytes)
     static_for<0, RH>([&](auto J) {
         constexpr int j = decltype(J)::value;
@@ -1986,7 +2001,7 @@ __device__ __forceinline__ void ims_body_t(const SpecArgs &a) {
                     constexpr int k = decltype(K)::value;
                     int acc = 0;
                     static_for<0, V.cw[k]>([&](auto X) { acc = sat(acc + mv[g & 1][k % G][decltype(X)::value]); });   // rows ascending, saturate per add :5568
-                    softv[k] = sat(iy[k] + acc);                                                                       // :5590-5597
+                    softv[k] = sat(iy_of(K) + acc);                                                                       // :5590-5597
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });

@@ -345,3 +345,36 @@ def test_two_gpu_ranks_with_the_real_decoder(L, torch):
     for o in outs:
         line = [ln for ln in o.splitlines() if ln.startswith("RESULT")][0]
         assert json.loads(line.split(" ", 2)[2]) == want
+
+
+def test_ldpc_sim_throughput_mode_with_interleaver_qam_and_device_list(L, torch, tmp_path):
+    """`ldpc_sim simulation --throughput --devices 0,0`: a jsonx scenario with 16-QAM + interleaver mode 3 (round 1 refused every
+    permutation_type but 0 in throughput mode) must give the FER / BER the C-ABI gives for the same noise, on two logical shards."""
+    import subprocess
+    from test_gpu_parity import _compat_lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _compat_lib(L)
+    exe = os.path.join(root, "ldpc-lib_amd", "ldpc_sim")
+    src = open(os.path.join(root, "examples", "simulation_appendix_c.jsonx")).read()
+    src = src.replace("modulation_type = 0", "modulation_type = 2").replace("permutation_type = 0", "permutation_type = 3")
+    src = src.replace("permutation_block = 128", "permutation_block = 64").replace("num_codewords = 2000", "num_codewords = 30000")
+    scen = tmp_path / "scen.jsonx"
+    scen.write_text(src)
+    out = str(tmp_path / "res.jsonx")
+    subprocess.check_call([exe, "simulation", str(scen), out, "--throughput", "--devices", "0,0"], stdout=subprocess.DEVNULL)
+
+    def get(path):
+        return subprocess.check_output([exe, "jsonx-get", out, path], text=True).strip()
+
+    def numbers(path):
+        return [float(x) for x in get(path).replace("array {", "").replace("}", "").split()]
+    # code #3 of the example: (2048,1024) min-sum 50 it at 2.0 and 2.5 dB -> the same points through the C-ABI on one context
+    assert int(get("results/3/_decoder_type")) == MS_DEC and int(get("results/3/_lifting")) == 64
+    snrs, fer, ber = numbers("results/3/_SNRs"), numbers("results/3/simulation_logs/0/FER"), numbers("results/3/simulation_logs/0/BER")
+    H = relift(load_base_matrix(), 64)
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        dec.set_interleaver(3, 64, 1)
+        for snr, f, b in zip(snrs, fer, ber):
+            s = dec.simulate(snr, 50, seed=1, first_frame=0, B=30001, modulation=2)
+            assert f == s["nde"] / 30001 and b == s["nse"] / 30001 / 1024, (snr, f, s)
+            assert s["nde"] > 0
