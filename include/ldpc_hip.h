@@ -63,7 +63,7 @@ int ldpc_hip_hard_words(const ldpc_hip_ctx *ctx); /* ceil(N/32): uint32 words pe
 /* Name of the decode kernel this context launches (code-specialised AOT / hiprtc instance, table-driven, generic). */
 const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *ctx);
 /* Name of the kernel the last ldpc_hip_decode_dev call on this context launched.  It differs from ldpc_hip_kernel_name only
- * for IMS_DEC with parameters beyond int8 (MS_DBITS > 8 or alpha > 1), which run on the table-driven int32 kernel. */
+ * for IMS_DEC with parameters beyond int8 (MS_DBITS > 8, MS_QBITS > 8 or alpha > 1), which run on the table-driven int32 kernel. */
 const char *ldpc_hip_last_launch(const ldpc_hip_ctx *ctx);
 
 /* Batched replacement of the decoder entry points (decoders.h:297,299,304; dispatch bp_simulation.cpp:716-729):

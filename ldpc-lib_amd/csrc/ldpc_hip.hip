@@ -513,11 +513,11 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
     }
     bool use_spec = c->spec_aot || c->spec_jit;
     const int ims_ialpha = (int)(alpha * (1 << 4));   // decoders.cpp:5458, MS_ALPHA_FPP = 4
-    if (use_spec && c->decoder_id == LDPC_HIP_IMS_DEC && (c->ims_dbits > 8 || ims_ialpha < 0 || ims_ialpha > 16)) {
+    if (use_spec && c->decoder_id == LDPC_HIP_IMS_DEC && (c->ims_dbits > 8 || c->ims_qbits > 8 || ims_ialpha < 0 || ims_ialpha > 16)) {
         if (!c->have_generic)
-            return fail(LDPC_HIP_EUNSUPPORTED, "integer min-sum with dbits=%d, alpha=%g needs the generic kernel, which does not support this code shape",
-                        c->ims_dbits, alpha);
-        use_spec = false;   // values beyond int8: table-driven int32 kernel
+            return fail(LDPC_HIP_EUNSUPPORTED, "integer min-sum with qbits=%d, dbits=%d, alpha=%g needs the generic kernel, which does not support this code shape",
+                        c->ims_qbits, c->ims_dbits, alpha);
+        use_spec = false;   // values beyond int8 (messages, or quantised inputs): table-driven int32 kernel
     }
     c->last_launch = (use_spec || c->global_tier) ? c->kernel_name.c_str() : c->generic_name.c_str();
     if (c->global_tier) {
