@@ -1749,6 +1749,11 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
     __syncthreads();
 
     bool fail = vote(syndrome_fail(true));                                          // :1742-1766
+    // Re-decode pass of the frame chain (frame_idx given, ldpc_hip.hip): the stale syndrome only enters this input check.  If the
+    // check fails now and failed in the earlier pass too (that pass returned non-zero: it iterated), every later step is the
+    // same as before -- the earlier outputs stand, nothing to redo.  Only a frame that is a codeword at the input (earlier
+    // result 0) or whose own syndrome equals the stale one can change.
+    if (a.frame_idx && fail && a.iters && a.iters[fr] != 0) return;
     int iter = 0;
     while (fail && iter < a.maxiter) {
         // ---- A: variable-node activation
