@@ -1,4 +1,4 @@
-// ldpc_global.hpp -- the shape-unlimited tier: min-sum, layered min-sum, sum-product and TDMP sum-product with the message state in
+// ldpc_global.hpp -- the shape-unlimited tier: min-sum, integer min-sum, layered min-sum, sum-product and TDMP sum-product with the message state in
 // GLOBAL memory.
 //
 // The LDS/VGPR-resident kernels (ldpc_spec.hpp, ldpc_kernels.hpp) need the a-posteriori values of a frame in one CU's LDS
@@ -9,6 +9,7 @@
 // phases.  The grid is capped and strides over the frames, so the workspace does not grow with the batch.
 //
 //   sp_global_kernel   sum_prod_decod_qc_lm  decoders.cpp:1923-2185: the four phases of ldpc_sumprod.hpp, arrays in the workspace.
+//   ims_global_kernel  imin_sum_decod_qc_lm  decoders.cpp:5430-5690: min-sum on ints, saturation after every add of STATE1 (:5568).
 //   tasp_global_kernel tdmp_sum_prod_gf2_decod_qc_lm  decoders.cpp:2584-2744 (decoder 7, the decoder of upstream's shipped scenarios):
 //                      per-edge lambda / rho / forward / backward products in the workspace instead of VGPRs, so row weight and
 //                      the number of circulants are unbounded (the resident tasp_body holds <= 144 edges in registers).
@@ -30,13 +31,15 @@
 
 namespace ldpc {
 
-constexpr int kGlobThreads = 256;
+constexpr int kGlobThreads = 1024;   // launch bound; the host launches 256 threads per frame for small codes, 1024 for large ones
+inline int glob_threads(int N) { return N >= 16384 ? 1024 : 256; }
 
 struct GlobArgs {
     DecArgs d;          // tables: row_start, edges, col_start, col_edges, col_slot
     char *ws;           // gridDim.x slices of ws_stride bytes
     size_t ws_stride;
     int ne;             // circulants
+    const double *ims_coef;   // ims_global_kernel: [B] sqrt(N / sum y^2) per frame (ims_coef_kernel: the sum is sequential, its rounding is part of the result)
 };
 
 // slice layout (all offsets 16-byte aligned)
@@ -68,7 +71,7 @@ __device__ inline void glob_outputs(const DecArgs &a, const GlobView &w, long lo
     const int N = a.N;
     if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
     if (a.hard) {
-        for (int wd = threadIdx.x; wd < a.hard_words; wd += kGlobThreads) {
+        for (int wd = threadIdx.x; wd < a.hard_words; wd += (int)blockDim.x) {
             uint32_t bits = 0;
             for (int b = 0; b < 32; ++b) {
                 const int v = 32 * wd + b;
@@ -78,7 +81,7 @@ __device__ inline void glob_outputs(const DecArgs &a, const GlobView &w, long lo
         }
     }
     if (a.soft_out)
-        for (int v = threadIdx.x; v < N; v += kGlobThreads) a.soft_out[fr * N + v] = w.soft[v];
+        for (int v = threadIdx.x; v < N; v += (int)blockDim.x) a.soft_out[fr * N + v] = w.soft[v];
 }
 
 __global__ void __launch_bounds__(kGlobThreads) ms_global_kernel(const GlobArgs g) {
@@ -88,13 +91,13 @@ __global__ void __launch_bounds__(kGlobThreads) ms_global_kernel(const GlobArgs 
     const GlobView w = glob_view(g.ws + (size_t)blockIdx.x * g.ws_stride, N, R, ne, M, 0);
     for (long long fr = blockIdx.x; fr < a.B; fr += gridDim.x) {
         const double *y = a.llr + fr * N;
-        for (int c = threadIdx.x; c < R; c += kGlobThreads) { w.m1[c] = 0.0; w.m2[c] = 0.0; w.pos[c] = 0; w.par[c] = 0; }   // :4579-4596
-        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += kGlobThreads) w.sgn[i] = 0;
+        for (int c = threadIdx.x; c < R; c += (int)blockDim.x) { w.m1[c] = 0.0; w.m2[c] = 0.0; w.pos[c] = 0; w.par[c] = 0; }   // :4579-4596
+        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += (int)blockDim.x) w.sgn[i] = 0;
         __syncthreads();
         int res = -a.maxiter;
         for (int iter = 0; iter < a.maxiter; ++iter) {
             // ---- STATE1 + STATE2 from the variable side (:4633-4685)
-            for (int v = threadIdx.x; v < N; v += kGlobThreads) {
+            for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {
                 const int k = v / M, i = v - k * M;
                 double acc = 0.0;                                                 // memset(soft, 0) :4630
                 for (int q = a.col_start[k]; q < a.col_start[k + 1]; ++q) {       // block rows ascending
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(kGlobThreads) ms_global_kernel(const GlobArgs 
             __syncthreads();
             // ---- STATE3 from the check side (:4690-4755)
             int fail = 0;
-            for (int chk = threadIdx.x; chk < R; chk += kGlobThreads) {
+            for (int chk = threadIdx.x; chk < R; chk += (int)blockDim.x) {
                 const int j = chk / M, n = chk - j * M;
                 const int e0 = a.row_start[j], e1 = a.row_start[j + 1];
                 const int po = w.pos[chk];
@@ -155,7 +158,7 @@ __global__ void __launch_bounds__(kGlobThreads) lms_global_kernel(const GlobArgs
     const GlobView w = glob_view(g.ws + (size_t)blockIdx.x * g.ws_stride, N, R, ne, M, 1);
     auto syndrome = [&]() -> int {                                                // check_syndrome, decoders.cpp:793-814
         int fail = 0;
-        for (int chk = threadIdx.x; chk < R; chk += kGlobThreads) {
+        for (int chk = threadIdx.x; chk < R; chk += (int)blockDim.x) {
             const int j = chk / M, n = chk - j * M;
             int synd = 0;
             for (int e = a.row_start[j]; e < a.row_start[j + 1]; ++e) {
@@ -170,9 +173,9 @@ __global__ void __launch_bounds__(kGlobThreads) lms_global_kernel(const GlobArgs
     };
     for (long long fr = blockIdx.x; fr < a.B; fr += gridDim.x) {
         const double *y = a.llr + fr * N;
-        for (int v = threadIdx.x; v < N; v += kGlobThreads) w.soft[v] = y[v];    // :5088
-        for (int c = threadIdx.x; c < R; c += kGlobThreads) { w.m1[c] = 0.0; w.m2[c] = 0.0; w.pos[c] = 0; w.par[c] = 0; }
-        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += kGlobThreads) w.sgn[i] = 0;
+        for (int v = threadIdx.x; v < N; v += (int)blockDim.x) w.soft[v] = y[v];    // :5088
+        for (int c = threadIdx.x; c < R; c += (int)blockDim.x) { w.m1[c] = 0.0; w.m2[c] = 0.0; w.pos[c] = 0; w.par[c] = 0; }
+        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += (int)blockDim.x) w.sgn[i] = 0;
         __syncthreads();
         int parity = syndrome();                                                   // :5111-5115
         int iter = 0;
@@ -180,7 +183,7 @@ __global__ void __launch_bounds__(kGlobThreads) lms_global_kernel(const GlobArgs
             if (parity == 0) break;                                                // :5119
             for (int j = 0; j < a.rh; ++j) {                                       // layers in sequence
                 const int e0 = a.row_start[j], e1 = a.row_start[j + 1];
-                for (int n = threadIdx.x; n < M; n += kGlobThreads) {
+                for (int n = threadIdx.x; n < M; n += (int)blockDim.x) {
                     const int chk = j * M + n;
                     const int po = w.pos[chk];
                     const uint8_t pa = w.par[chk];
@@ -234,7 +237,7 @@ __global__ void __launch_bounds__(kGlobThreads) tasp_global_kernel(const GlobArg
     double *const Z = w.tmp, *const Y = w.tmp + EM, *const SF = w.tmp + 2 * EM, *const SB = w.tmp + 3 * EM;   // [e * M + k]
     auto syndrome = [&]() -> int {                                                  // check_syndrome_thr :2274-2306, thr 0.5
         int fail = 0;
-        for (int chk = threadIdx.x; chk < R; chk += kGlobThreads) {
+        for (int chk = threadIdx.x; chk < R; chk += (int)blockDim.x) {
             const int j = chk / M, n = chk - j * M;
             int synd = 0;
             for (int e = a.row_start[j]; e < a.row_start[j + 1]; ++e) {
@@ -248,13 +251,13 @@ __global__ void __launch_bounds__(kGlobThreads) tasp_global_kernel(const GlobArg
         return __syncthreads_or(fail);
     };
     for (long long fr = blockIdx.x; fr < a.B; fr += gridDim.x) {
-        for (int v = threadIdx.x; v < N; v += kGlobThreads) {                       // :2611-2618
+        for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {                       // :2611-2618
             const double x = a.llr[fr * N + v] * 0.5;
             const double y = x < 20.0 ? (x < -20.0 ? -20.0 : x) : 20.0;             // maxd(mind(x, INPUT_LIMIT), -INPUT_LIMIT)
             const double e0 = ldpc_spec::exp_glibc(y), e1 = ldpc_spec::exp_glibc(-y);
             w.soft[v] = e1 / (e0 + e1);
         }
-        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += kGlobThreads) Z[i] = 0.5;   // :2637
+        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += (int)blockDim.x) Z[i] = 0.5;   // :2637
         __syncthreads();
         int synd = syndrome();                                                      // :2653-2660
         int steps = 0;
@@ -262,7 +265,7 @@ __global__ void __launch_bounds__(kGlobThreads) tasp_global_kernel(const GlobArg
             while (steps < a.maxiter) {
                 for (int j = 0; j < a.rh; ++j) {                                    // layers in sequence (:2668)
                     const int e0 = a.row_start[j], e1 = a.row_start[j + 1], rw = e1 - e0;
-                    for (int k = threadIdx.x; k < M; k += kGlobThreads) {
+                    for (int k = threadIdx.x; k < M; k += (int)blockDim.x) {
                         for (int e = e0; e < e1; ++e) {                             // :2676-2697
                             const uint32_t d = a.edges[e];
                             int i = k + (int)(d & 0xffffu);
@@ -322,7 +325,7 @@ __global__ void __launch_bounds__(kGlobThreads) sp_global_kernel(const GlobArgs 
     auto maxd = [](double x, double y) { return x < y ? y : x; };
     auto syndrome = [&]() -> int {                                                  // :1964-2002 / :2129-2149
         int fail = 0;
-        for (int chk = threadIdx.x; chk < R; chk += kGlobThreads) {
+        for (int chk = threadIdx.x; chk < R; chk += (int)blockDim.x) {
             const int j = chk / M, n = chk - j * M;
             int synd = 0;
             for (int e = a.row_start[j]; e < a.row_start[j + 1]; ++e) {
@@ -336,17 +339,17 @@ __global__ void __launch_bounds__(kGlobThreads) sp_global_kernel(const GlobArgs 
         return __syncthreads_or(fail);
     };
     for (long long fr = blockIdx.x; fr < a.B; fr += gridDim.x) {
-        for (int v = threadIdx.x; v < N; v += kGlobThreads) {                       // :1947-1951
+        for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {                       // :1947-1951
             const double yl = maxd(mind(a.llr[fr * N + v], 20.0), -20.0);
             yd[v] = w.soft[v] = ldpc_spec::exp_glibc(yl);
         }
-        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += kGlobThreads) ZZ[i] = 1.0;   // :1957-1959
+        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += (int)blockDim.x) ZZ[i] = 1.0;   // :1957-1959
         __syncthreads();
         int res = -a.maxiter;
         bool conv = syndrome() == 0;
         if (conv) res = 0;
         for (int iter = 0; !conv && iter < a.maxiter; ++iter) {
-            for (int v = threadIdx.x; v < N; v += kGlobThreads) {                   // phase A :2017-2060
+            for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {                   // phase A :2017-2060
                 const int k = v / M, t = v - k * M;
                 const int c0 = a.col_start[k], c1 = a.col_start[k + 1];
                 double prefix = yd[v];
@@ -360,7 +363,7 @@ __global__ void __launch_bounds__(kGlobThreads) sp_global_kernel(const GlobArgs 
                 }
             }
             __syncthreads();
-            for (int chk = threadIdx.x; chk < R; chk += kGlobThreads) {             // phase B :2047-2050
+            for (int chk = threadIdx.x; chk < R; chk += (int)blockDim.x) {             // phase B :2047-2050
                 const int j = chk / M, n = chk - j * M;
                 double s = 1.0;
                 for (int e = a.row_start[j]; e < a.row_start[j + 1]; ++e) {
@@ -371,7 +374,7 @@ __global__ void __launch_bounds__(kGlobThreads) sp_global_kernel(const GlobArgs 
                 S[chk] = s;
             }
             __syncthreads();
-            for (int v = threadIdx.x; v < N; v += kGlobThreads) {                   // phase C :2103-2127
+            for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {                   // phase C :2103-2127
                 const int k = v / M, t = v - k * M;
                 double soft = yd[v];
                 for (int u = a.col_start[k]; u < a.col_start[k + 1]; ++u) {
@@ -392,6 +395,96 @@ __global__ void __launch_bounds__(kGlobThreads) sp_global_kernel(const GlobArgs 
             if (syndrome() == 0) { conv = true; res = iter + 1; }                   // :2151-2166
         }
         glob_outputs<2>(a, w, fr, res);
+        __syncthreads();
+    }
+}
+
+// imin_sum_decod_qc_lm, decoders.cpp:5430-5690 (MS_MUL_CORRECTION build: c2v magnitude (min * ialpha) >> 4 in STATE1 and STATE3).
+// IMS_DATA is a short upstream; every intermediate fits (|values| <= 2 * max_data < 2^15), so int arithmetic gives the same numbers.
+// Workspace: soft / iy as ints in the soft / aux arrays, min1 / min2 as ints in m1 / m2.
+__global__ void __launch_bounds__(kGlobThreads) ims_global_kernel(const GlobArgs g) {
+    const DecArgs &a = g.d;
+    const int M = a.M, N = a.N, R = a.rh * M, ne = g.ne;
+    const GlobView w = glob_view(g.ws + (size_t)blockIdx.x * g.ws_stride, N, R, ne, M, 0);
+    int *const soft = reinterpret_cast<int *>(w.soft), *const iy = reinterpret_cast<int *>(w.aux);
+    int *const m1 = reinterpret_cast<int *>(w.m1), *const m2 = reinterpret_cast<int *>(w.m2);
+    const int max_data = (1 << (a.ims_dbits - 1)) - 1;   // :5445
+    const int max_quant = (1 << (a.ims_qbits - 1)) - 1;  // :5446
+    const int ialpha = (int)(a.alpha * (1 << 4));         // :5458 MS_ALPHA_FPP = 4
+    auto sat = [&](int x) { return x > max_data ? max_data : (x < -max_data ? -max_data : x); };   // limit_val :4308
+    for (long long fr = blockIdx.x; fr < a.B; fr += gridDim.x) {
+        const double coef = g.ims_coef[fr];
+        for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {                    // :5472-5500
+            double val = a.llr[fr * N + v];
+            int sign = 0;
+            if (val < 0) { val = -val; sign = 1; }
+            val *= coef;
+            if (val > a.ims_thr) val = a.ims_thr;
+            const int ival = (int)(short)floor(val * max_quant / a.ims_thr + 0.5);
+            iy[v] = sign ? -ival : ival;
+        }
+        for (int c = threadIdx.x; c < R; c += (int)blockDim.x) { m1[c] = 0; m2[c] = 0; w.pos[c] = 0; w.par[c] = 0; }   // :5462-5470
+        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += (int)blockDim.x) w.sgn[i] = 0;
+        __syncthreads();
+        int res = -a.maxiter;
+        for (int iter = 0; iter < a.maxiter; ++iter) {
+            for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {                // STATE1 + STATE2 from the variable side (:5540-5604)
+                const int k = v / M, i = v - k * M;
+                int acc = 0;
+                for (int q = a.col_start[k]; q < a.col_start[k + 1]; ++q) {         // block rows ascending: saturation after EVERY add (:5568)
+                    const uint32_t d = a.col_edges[q];
+                    const int j = (int)(d >> 16), c = (int)(d & 0xffffu), e = (int)a.col_slot[q];
+                    int n = i - c;
+                    if (n < 0) n += M;
+                    const int chk = j * M + n;
+                    int tmp = w.pos[chk] == e - a.row_start[j] ? m2[chk] : m1[chk];
+                    tmp = (tmp * ialpha) >> 4;                                       // :5554
+                    const int cv = (w.sgn[(size_t)e * M + n] ^ w.par[chk]) ? -tmp : tmp;
+                    acc = sat(acc + cv);
+                }
+                soft[v] = sat(iy[v] + acc);                                         // :5590-5601
+            }
+            __syncthreads();
+            int fail = 0;
+            for (int chk = threadIdx.x; chk < R; chk += (int)blockDim.x) {          // STATE3 (:5610-5678)
+                const int j = chk / M, n = chk - j * M;
+                const int e0 = a.row_start[j], e1 = a.row_start[j + 1];
+                const int po = w.pos[chk], o1 = m1[chk], o2 = m2[chk];
+                const uint8_t pa = w.par[chk];
+                int nm1 = max_data, nm2 = max_data, np = 0, synd = 0;
+                uint8_t npar = 0;
+                for (int e = e0; e < e1; ++e) {
+                    const uint32_t d = a.edges[e];
+                    int i = n + (int)(d & 0xffffu);
+                    if (i >= M) i -= M;
+                    const int r = soft[(int)(d >> 16) * M + i];
+                    synd ^= (int)(r < 0);
+                    const int val = ((po == e - e0 ? o2 : o1) * ialpha) >> 4;       // :5640
+                    const int t = (w.sgn[(size_t)e * M + n] ^ pa) ? -val : val;
+                    const int msg = r - t;
+                    const uint8_t sign = msg < 0;
+                    w.sgn[(size_t)e * M + n] = sign;
+                    npar ^= sign;
+                    int v = msg < 0 ? -msg : msg;
+                    v = v > max_data ? max_data : v;
+                    if (v < nm1) { np = e - e0; nm2 = nm1; nm1 = v; }
+                    else if (v < nm2) nm2 = v;
+                }
+                m1[chk] = nm1; m2[chk] = nm2; w.pos[chk] = np; w.par[chk] = npar;
+                fail |= synd;
+            }
+            if (!__syncthreads_or(fail)) { res = iter + 1; break; }                 // :5684-5689
+        }
+        if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
+        if (a.hard) {
+            for (int wd = threadIdx.x; wd < a.hard_words; wd += (int)blockDim.x) {
+                uint32_t bits = 0;
+                for (int b = 0; b < 32; ++b) if (32 * wd + b < N) bits |= (uint32_t)(soft[32 * wd + b] < 0) << b;
+                a.hard[fr * a.hard_words + wd] = bits;
+            }
+        }
+        if (a.soft_out)
+            for (int v = threadIdx.x; v < N; v += (int)blockDim.x) a.soft_out[fr * N + v] = (double)soft[v];
         __syncthreads();
     }
 }

@@ -426,20 +426,22 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
         }
     }
     const char *genv = getenv("LDPC_HIP_FORCE_GLOBAL");   // tests: run the shape-unlimited tier on shapes the resident kernels take
-    const bool can_global = decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || decoder_id == LDPC_HIP_SP_DEC ||
+    const bool can_global = decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || decoder_id == LDPC_HIP_SP_DEC || decoder_id == LDPC_HIP_IMS_DEC ||
                             (decoder_id == LDPC_HIP_TASP_DEC && t.min_rw >= 2);
     if (can_global && ((genv && atoi(genv) != 0) || (!c->spec_aot && !c->spec_jit && !have_generic))) {
         c->global_tier = true;
         c->spec_aot = nullptr; c->spec_jit = nullptr;
-        c->kernel_name = decoder_id == LDPC_HIP_MS_DEC ? "ms_global_kernel" : decoder_id == LDPC_HIP_LMS_DEC ? "lms_global_kernel" :
+        c->kernel_name = decoder_id == LDPC_HIP_MS_DEC ? "ms_global_kernel" : decoder_id == LDPC_HIP_LMS_DEC ? "lms_global_kernel" : decoder_id == LDPC_HIP_IMS_DEC ? "ims_global_kernel" :
                          decoder_id == LDPC_HIP_SP_DEC ? "sp_global_kernel" : "tasp_global_kernel";
-        c->glob_stride = ldpc::glob_ws_bytes(c->N, c->R, t.ne, M, decoder_id == LDPC_HIP_MS_DEC ? 0 : decoder_id == LDPC_HIP_TASP_DEC ? 4 : 1);
+        c->glob_stride = ldpc::glob_ws_bytes(c->N, c->R, t.ne, M, (decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_IMS_DEC) ? 0 : decoder_id == LDPC_HIP_TASP_DEC ? 4 : 1);
     }
+    if (decoder_id == LDPC_HIP_IMS_DEC && !c->global_tier)   // parameters beyond int8 may send a launch to the global tier later
+        c->glob_stride = ldpc::glob_ws_bytes(c->N, c->R, t.ne, M, 0);
     if (!c->spec_aot && !c->spec_jit && !c->global_tier) {
         if (!have_generic)
             return fail(LDPC_HIP_EUNSUPPORTED, "decoder %d, code %dx%d lifting %d: not supported by the generic kernel (limits: %d block rows, "
                         "%d block columns, row weight %d, M <= 512, 160 KiB LDS), no code-specialised instance: %s; the shape-unlimited "
-                        "tier serves sum-product (1), min-sum (3), TDMP sum-product (7) and layered min-sum (8) only",
+                        "tier serves sum-product (1), min-sum (3), integer min-sum (4), TDMP sum-product (7) and layered min-sum (8) only",
                         decoder_id, rh, nh, M, kRHM, kNHM, kRWM, why_not.c_str());
         if (plan.body && c->variant >= 2)
             fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", why_not.c_str(), c->kernel_name.c_str());
@@ -512,15 +514,14 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
         HIP_TRY(hipEventRecord(ev0, stream));
     }
     bool use_spec = c->spec_aot || c->spec_jit;
+    bool use_global = c->global_tier;
     const int ims_ialpha = (int)(alpha * (1 << 4));   // decoders.cpp:5458, MS_ALPHA_FPP = 4
     if (use_spec && c->decoder_id == LDPC_HIP_IMS_DEC && (c->ims_dbits > 8 || c->ims_qbits > 8 || ims_ialpha < 0 || ims_ialpha > 16)) {
-        if (!c->have_generic)
-            return fail(LDPC_HIP_EUNSUPPORTED, "integer min-sum with qbits=%d, dbits=%d, alpha=%g needs the generic kernel, which does not support this code shape",
-                        c->ims_qbits, c->ims_dbits, alpha);
-        use_spec = false;   // values beyond int8 (messages, or quantised inputs): table-driven int32 kernel
+        use_spec = false;   // values beyond int8 (messages, or quantised inputs): table-driven int32 kernel, or the global tier's
+        if (!c->have_generic) use_global = true;
     }
-    c->last_launch = (use_spec || c->global_tier) ? c->kernel_name.c_str() : c->generic_name.c_str();
-    if (c->global_tier) {
+    c->last_launch = use_global ? (c->global_tier ? c->kernel_name.c_str() : "ims_global_kernel") : use_spec ? c->kernel_name.c_str() : c->generic_name.c_str();
+    if (use_global) {
         // one workgroup per frame, capped: the workspace is per workgroup and does not grow with the batch
         int grid = (int)(B < 1024 ? B : 1024);
         while (grid > 16 && (size_t)grid * c->glob_stride > ((size_t)8 << 30)) grid /= 2;
@@ -537,10 +538,24 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
         ga.d.B = B; ga.d.rh = c->rh; ga.d.nh = c->nh; ga.d.M = c->M; ga.d.N = c->N; ga.d.F = 1; ga.d.maxiter = maxiter;
         ga.d.hard_words = c->hard_words; ga.d.alpha = alpha;
         ga.ws = c->d_glob_ws; ga.ws_stride = c->glob_stride; ga.ne = c->ne;
-        if (c->decoder_id == LDPC_HIP_MS_DEC) hipLaunchKernelGGL(ldpc::ms_global_kernel, dim3((unsigned)grid), dim3(ldpc::kGlobThreads), 0, stream, ga);
-        else if (c->decoder_id == LDPC_HIP_LMS_DEC) hipLaunchKernelGGL(ldpc::lms_global_kernel, dim3((unsigned)grid), dim3(ldpc::kGlobThreads), 0, stream, ga);
-        else if (c->decoder_id == LDPC_HIP_SP_DEC) hipLaunchKernelGGL(ldpc::sp_global_kernel, dim3((unsigned)grid), dim3(ldpc::kGlobThreads), 0, stream, ga);
-        else hipLaunchKernelGGL(ldpc::tasp_global_kernel, dim3((unsigned)grid), dim3(ldpc::kGlobThreads), 0, stream, ga);
+        if (c->decoder_id == LDPC_HIP_IMS_DEC) {
+            if (B > c->ims_coef_frames) {
+                if (c->d_ims_coef) (void)hipFree(c->d_ims_coef);
+                c->d_ims_coef = nullptr; c->ims_coef_frames = 0;
+                HIP_TRY(hipMalloc(&c->d_ims_coef, sizeof(double) * (size_t)B));
+                c->ims_coef_frames = B;
+            }
+            ldpc::ImsCoefArgs ca{d_llr, c->d_ims_coef, B, c->N};
+            hipLaunchKernelGGL(ldpc::ims_coef_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, ca);
+            HIP_TRY(hipGetLastError());
+            ga.ims_coef = c->d_ims_coef;
+            ga.d.ims_thr = c->ims_thr; ga.d.ims_qbits = c->ims_qbits; ga.d.ims_dbits = c->ims_dbits;
+        }
+        if (c->decoder_id == LDPC_HIP_MS_DEC) hipLaunchKernelGGL(ldpc::ms_global_kernel, dim3((unsigned)grid), dim3((unsigned)ldpc::glob_threads(c->N)), 0, stream, ga);
+        else if (c->decoder_id == LDPC_HIP_LMS_DEC) hipLaunchKernelGGL(ldpc::lms_global_kernel, dim3((unsigned)grid), dim3((unsigned)ldpc::glob_threads(c->N)), 0, stream, ga);
+        else if (c->decoder_id == LDPC_HIP_IMS_DEC) hipLaunchKernelGGL(ldpc::ims_global_kernel, dim3((unsigned)grid), dim3((unsigned)ldpc::glob_threads(c->N)), 0, stream, ga);
+        else if (c->decoder_id == LDPC_HIP_SP_DEC) hipLaunchKernelGGL(ldpc::sp_global_kernel, dim3((unsigned)grid), dim3((unsigned)ldpc::glob_threads(c->N)), 0, stream, ga);
+        else hipLaunchKernelGGL(ldpc::tasp_global_kernel, dim3((unsigned)grid), dim3((unsigned)ldpc::glob_threads(c->N)), 0, stream, ga);
     } else if (use_spec) {
         // code-specialised kernel: one frame per workgroup
         ldpc_spec::SpecArgs sa{};

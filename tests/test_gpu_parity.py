@@ -176,7 +176,7 @@ def test_maxiter_one_and_unsupported_shapes(L):
     with L.LdpcHip(MS_DEC, np.zeros((70, 140), dtype=np.int16), 64) as dec:   # more block rows than any resident kernel holds:
         assert "ms_global_kernel" in dec.kernel_name                            # the shape-unlimited tier takes it (tests/test_gpu_shapes.py)
     with pytest.raises(L.LdpcHipError):
-        L.LdpcHip(IMS_DEC, np.zeros((70, 140), dtype=np.int16), 64)             # no such tier for integer min-sum: loud, no fallback
+        L.LdpcHip(BP_DEC, np.zeros((70, 140), dtype=np.int16), 64)              # no such tier for Gallager BP: loud, no fallback
 
 
 def test_full_size_properties(L, torch):

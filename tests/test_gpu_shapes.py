@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from ldpc_testlib import (GOLDEN_DIR, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Oracle, awgn_llr, load_base_matrix, pack_bits, random_qc_code,
+from ldpc_testlib import (GOLDEN_DIR, IMS_DEC, LMS_DEC, MS_DEC, SP_DEC, TASP_DEC, Oracle, awgn_llr, load_base_matrix, pack_bits, random_qc_code,
                           relift)
 
 pytestmark = pytest.mark.gpu
@@ -91,7 +91,7 @@ GLOBAL_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("dec_id", [MS_DEC, LMS_DEC, TASP_DEC, SP_DEC])
+@pytest.mark.parametrize("dec_id", [MS_DEC, LMS_DEC, TASP_DEC, SP_DEC, IMS_DEC])
 @pytest.mark.parametrize("why,rh,nh,M,weights,snr", GLOBAL_SHAPES)
 def test_shapes_beyond_the_resident_kernels_run_on_the_global_tier(L, torch, dec_id, why, rh, nh, M, weights, snr):
     rng = np.random.RandomState(rh * 1000 + nh)
@@ -108,7 +108,7 @@ def test_shapes_beyond_the_resident_kernels_run_on_the_global_tier(L, torch, dec
                 H[j, rh + rng.randint(0, nh - rh - 1)] = rng.randint(0, M)
     frames = 6 if M >= 600 else 16
     # (an empty column only rules out the code-specialised bodies: the table-driven kernels of min-sum / layered min-sum take it)
-    expect = None if ("empty" in why and dec_id in (MS_DEC, LMS_DEC)) else "_global_kernel"
+    expect = None if ("empty" in why and dec_id in (MS_DEC, LMS_DEC, IMS_DEC)) else "_global_kernel"
     if dec_id == SP_DEC and M < 600:
         expect = None        # the table-driven sum-product kernel has no block-row / row-weight limits: it takes the small shapes itself
     name, it = _check(L, torch, dec_id, H, M, _llr(H, M, snr, 3, frames), 15 if dec_id == TASP_DEC else 30, expect_kernel=expect)
@@ -116,14 +116,14 @@ def test_shapes_beyond_the_resident_kernels_run_on_the_global_tier(L, torch, dec
 
 def test_decoders_without_a_global_tier_still_fail_loudly(L, torch):
     H = relift(load_base_matrix(), 600)
-    from ldpc_testlib import ASP_DEC, BP_DEC, IMS_DEC
-    for dec_id in (ASP_DEC, BP_DEC, IMS_DEC):
+    from ldpc_testlib import ASP_DEC, BP_DEC
+    for dec_id in (ASP_DEC, BP_DEC):
         with pytest.raises(L.LdpcHipError, match="shape-unlimited"):
             L.LdpcHip(dec_id, H, 600)
 
 
 @pytest.mark.parametrize("name", ["ms_m64_1p2", "ms_m126_1p7", "ms_m1_4p0", "ms_m512_1p6", "lms_m64_0p8", "lms_m512_1p0", "lms_m1_4p0",
-                                  "tasp_m64_1p7", "tasp_m126_1p7", "tasp_m1_4p0", "sp_m64_1p2", "sp_m64_2p0", "sp_m1_4p0"])
+                                  "tasp_m64_1p7", "tasp_m126_1p7", "tasp_m1_4p0", "sp_m64_1p2", "sp_m64_2p0", "sp_m1_4p0", "ims_m64_2p0"])
 def test_global_tier_on_the_compiled_references_vectors(L, torch, name, monkeypatch):
     """LDPC_HIP_FORCE_GLOBAL=1: the tier takes shapes the resident kernels normally serve, so it can be pinned by the golden
     vectors the compiled upstream code produced: hard bits, return values, soft values."""
