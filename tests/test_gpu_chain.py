@@ -378,3 +378,17 @@ def test_ldpc_sim_throughput_mode_with_interleaver_qam_and_device_list(L, torch,
             s = dec.simulate(snr, 50, seed=1, first_frame=0, B=30001, modulation=2)
             assert f == s["nde"] / 30001 and b == s["nse"] / 30001 / 1024, (snr, f, s)
             assert s["nde"] > 0
+
+
+def test_multi_gpu_c_example_runs(L, tmp_path):
+    """examples/simulate_multi.c end to end (every GPU of the box, RCCL when there is more than one... one here): random codewords,
+    16-QAM, block interleaver; FER in the range the Python route measures for the same point."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "simulate_multi")
+    subprocess.check_call(["gcc", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "simulate_multi.c"), "-o", exe,
+                           "-L", os.path.join(root, "ldpc-lib_amd"), "-lldpc_hip", "-Wl,-rpath," + os.path.join(root, "ldpc-lib_amd")])
+    out = subprocess.check_output([exe, os.path.join(GOLDEN_DIR, "h16x32_m126.txt"), "64", "3", "50", "5.2", "60000"], text=True)
+    row = [ln for ln in out.splitlines() if ln.startswith("Eb/N0")][0].split()
+    fer = float(row[row.index("FER") + 1])
+    assert int(row[row.index("frames") + 1]) == 60000 and 0.02 < fer < 0.07, out

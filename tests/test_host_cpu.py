@@ -154,12 +154,13 @@ def test_two_rank_gloo_run_matches_single_process():
 
 
 def test_c_example_builds_against_the_header(tmp_path):
-    """examples/simulate.c is plain C: the header must be C-clean and the library must link from gcc."""
-    exe = tmp_path / "simulate"
-    subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "simulate.c"),
-                           "-o", str(exe), "-L", os.path.join(ROOT, "ldpc-lib_amd"), "-lldpc_hip",
-                           "-Wl,-rpath," + os.path.join(ROOT, "ldpc-lib_amd")])
-    assert exe.exists()
+    """examples/simulate.c and simulate_multi.c are plain C: the header must be C-clean and the library must link from gcc."""
+    for name in ("simulate", "simulate_multi"):
+        exe = tmp_path / name
+        subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"),
+                               "-o", str(exe), "-L", os.path.join(ROOT, "ldpc-lib_amd"), "-lldpc_hip",
+                               "-Wl,-rpath," + os.path.join(ROOT, "ldpc-lib_amd")])
+        assert exe.exists()
 
 
 # ---- jsonx reader / writer and the `ldpc_sim` driver (SURVEY 8f f3) -------------------------------------------------------
