@@ -10,6 +10,8 @@
 //
 //   sp_global_kernel   sum_prod_decod_qc_lm  decoders.cpp:1923-2185: the four phases of ldpc_sumprod.hpp, arrays in the workspace.
 //   ims_global_kernel  imin_sum_decod_qc_lm  decoders.cpp:5430-5690: min-sum on ints, saturation after every add of STATE1 (:5568).
+//   bp_global_kernel   bp_decod_qc_lm        decoders.cpp:1708-1920, with the frame chain of the resident kernel.
+//   asp_global_kernel  sum_prod_gf2_decod_qc_lm  decoders.cpp:2324-2581 (general branch).
 //   tasp_global_kernel tdmp_sum_prod_gf2_decod_qc_lm  decoders.cpp:2584-2744 (decoder 7, the decoder of upstream's shipped scenarios):
 //                      per-edge lambda / rho / forward / backward products in the workspace instead of VGPRs, so row weight and
 //                      the number of circulants are unbounded (the resident tasp_body holds <= 144 edges in registers).
@@ -39,6 +41,11 @@ struct GlobArgs {
     char *ws;           // gridDim.x slices of ws_stride bytes
     size_t ws_stride;
     int ne;             // circulants
+    // bp_global_kernel only: the frame chain (see SpecArgs in ldpc_spec.hpp; same layouts)
+    const uint32_t *stale;    // [B][rh * ceil(M/64)] u64 words, bit = lane: syndrome the previous frame left behind, or null
+    uint32_t *synd_out;       // same layout: what this frame leaves behind, or null
+    const int *frame_idx;     // [slots] frame decoded by each workgroup slot, or null = the slot index
+    long long slots;          // workgroup slots of this launch (B, or the number of frames of a re-decode pass)
     const double *ims_coef;   // ims_global_kernel: [B] sqrt(N / sum y^2) per frame (ims_coef_kernel: the sum is sequential, its rounding is part of the result)
 };
 
@@ -485,6 +492,202 @@ __global__ void __launch_bounds__(kGlobThreads) ims_global_kernel(const GlobArgs
         }
         if (a.soft_out)
             for (int v = threadIdx.x; v < N; v += (int)blockDim.x) a.soft_out[fr * N + v] = (double)soft[v];
+        __syncthreads();
+    }
+}
+
+// sum_prod_gf2_decod_qc_lm, decoders.cpp:2324-2581 (probability domain, flooding; general branch :2482-2556 -- codes whose block
+// columns ALL have weight 2 take upstream's other branch and are refused by the host like in the resident tier).
+// Workspace: state[e][n] per circulant and check (upstream's state[slot][row*m + n]) + two scratch arrays for map_bin's forward /
+// backward products; channel P(bit = 1) in aux, a-posteriori values in soft.
+__global__ void __launch_bounds__(kGlobThreads) asp_global_kernel(const GlobArgs g) {
+    const DecArgs &a = g.d;
+    const int M = a.M, N = a.N, R = a.rh * M, ne = g.ne;
+    const GlobView w = glob_view(g.ws + (size_t)blockIdx.x * g.ws_stride, N, R, ne, M, 3);
+    const size_t EM = glob_align(sizeof(double) * (size_t)ne * M) / sizeof(double);
+    double *const ST = w.tmp, *const SF = w.tmp + EM, *const SB = w.tmp + 2 * EM, *const p1ch = w.aux;
+    auto mind = [](double x, double y) { return x < y ? x : y; };
+    auto maxd = [](double x, double y) { return x < y ? y : x; };
+    auto syndrome = [&]() -> int {                                                  // check_syndrome_thr :2274-2306, thr 0.5
+        int fail = 0;
+        for (int chk = threadIdx.x; chk < R; chk += (int)blockDim.x) {
+            const int j = chk / M, n = chk - j * M;
+            int synd = 0;
+            for (int e = a.row_start[j]; e < a.row_start[j + 1]; ++e) {
+                const uint32_t d = a.edges[e];
+                int i = n + (int)(d & 0xffffu);
+                if (i >= M) i -= M;
+                synd ^= (int)(w.soft[(int)(d >> 16) * M + i] > 0.5);
+            }
+            fail |= synd;
+        }
+        return __syncthreads_or(fail);
+    };
+    for (long long fr = blockIdx.x; fr < a.B; fr += gridDim.x) {
+        for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {                    // :2351-2379
+            const int k = v / M, t = v - k * M;
+            const double x = a.llr[fr * N + v] * 0.5;
+            const double y = maxd(mind(x, 20.0), -20.0);
+            const double e0 = ldpc_spec::exp_glibc(y), e1 = ldpc_spec::exp_glibc(-y);
+            const double p = e1 / (e0 + e1);
+            p1ch[v] = w.soft[v] = p;
+            for (int q = a.col_start[k]; q < a.col_start[k + 1]; ++q) {             // state <- rotated channel probability
+                int nn = t - (int)(a.col_edges[q] & 0xffffu);
+                if (nn < 0) nn += M;
+                ST[(size_t)a.col_slot[q] * M + nn] = p;
+            }
+        }
+        __syncthreads();
+        int synd = syndrome();                                                      // :2393-2399
+        int steps = 0;
+        while (synd != 0 && steps < a.maxiter) {
+            for (int chk = threadIdx.x; chk < R; chk += (int)blockDim.x) {          // check nodes: map_bin(&state[0][i*m+k], rw, r) :2191-2228
+                const int j = chk / M, n = chk - j * M;
+                const int e0 = a.row_start[j], rw = a.row_start[j + 1] - e0;
+                auto st = [&](int i) -> double & { return ST[(size_t)(e0 + i) * M + n]; };
+                auto sf = [&](int i) -> double & { return SF[(size_t)(e0 + i) * M + n]; };
+                auto sb = [&](int i) -> double & { return SB[(size_t)(e0 + i) * M + n]; };
+                auto P = [&](int i) { return 1 - 2 * st(i); };
+                sf(0) = P(0);
+                for (int i = 1; i < rw - 1; ++i) sf(i) = P(i) * sf(i - 1);
+                sb(rw - 1) = P(rw - 1);
+                for (int i = rw - 2; i > 0; --i) sb(i) = P(i) * sb(i + 1);
+                st(0) = (1 - sb(1)) / 2;
+                for (int i = 1; i < rw - 1; ++i) st(i) = (1 - sf(i - 1) * sb(i + 1)) / 2;
+                st(rw - 1) = (1 - sf(rw - 2)) / 2;
+            }
+            __syncthreads();
+            for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {                // symbol nodes + local data update :2482-2556
+                const int k = v / M, t = v - k * M;
+                double P1 = p1ch[v], P0 = 1 - p1ch[v];
+                for (int q = a.col_start[k]; q < a.col_start[k + 1]; ++q) {         // rows ascending
+                    int nn = t - (int)(a.col_edges[q] & 0xffffu);
+                    if (nn < 0) nn += M;
+                    const double d = ST[(size_t)a.col_slot[q] * M + nn];
+                    P1 *= d;
+                    P0 *= 1 - d;
+                }
+                const double so = P1 / (P0 + P1);
+                w.soft[v] = so;
+                for (int q = a.col_start[k]; q < a.col_start[k + 1]; ++q) {
+                    int nn = t - (int)(a.col_edges[q] & 0xffffu);
+                    if (nn < 0) nn += M;
+                    const size_t zi = (size_t)a.col_slot[q] * M + nn;
+                    const double sos = ST[zi];
+                    const double p1 = so / sos;
+                    const double p0 = (1 - so) / (1 - sos);
+                    const double dd = p1 / (p1 + p0);
+                    ST[zi] = maxd(mind(dd, 1.0 - 0.000001), 0.000001);              // SP_DEC_MAX_VAL / SP_DEC_MIN_VAL :96-97
+                }
+            }
+            __syncthreads();
+            synd = syndrome();                                                      // :2566
+            steps = steps + 1;
+        }
+        glob_outputs<1>(a, w, fr, synd ? -steps : steps);                           // 0: codeword at the input; converged after `steps`; else -steps
+        __syncthreads();
+    }
+}
+
+// bp_decod_qc_lm, decoders.cpp:1708-1920 (Gallager BP in the log domain), the phases of bp_body (ldpc_spec.hpp) with every array in
+// the workspace: ZZ[e][t] per edge and variable position (tmp), BB in sgn, the check sums s in m1 and their signs in par, yd in aux,
+// the a-posteriori LLRs in soft.  exp / log are glibc's algorithms (tables read from global memory here).  The frame chain
+// (stale syndrome in, syndrome left behind out, re-decode passes) works exactly as in the resident kernel.
+__global__ void __launch_bounds__(kGlobThreads) bp_global_kernel(const GlobArgs g) {
+    const DecArgs &a = g.d;
+    const int M = a.M, N = a.N, R = a.rh * M, ne = g.ne, CH = (M + 63) / 64;
+    const GlobView w = glob_view(g.ws + (size_t)blockIdx.x * g.ws_stride, N, R, ne, M, 1);
+    double *const ZZ = w.tmp, *const yd = w.aux, *const S = w.m1;
+    uint8_t *const BB = w.sgn, *const bs = w.par;
+    uint8_t *const left = reinterpret_cast<uint8_t *>(w.pos);                       // [R] syndrome bits as last computed (upstream's st->syndr)
+    auto mind = [](double x, double y) { return x < y ? x : y; };
+    auto maxd = [](double x, double y) { return x < y ? y : x; };
+    for (long long slot = blockIdx.x; slot < g.slots; slot += gridDim.x) {
+        const long long fr = g.frame_idx ? g.frame_idx[slot] : slot;
+        auto syndrome = [&](bool with_stale) -> int {                               // :1742-1766 / :1869-1893
+            int fail = 0;
+            for (int chk = threadIdx.x; chk < R; chk += (int)blockDim.x) {
+                const int j = chk / M, n = chk - j * M;
+                int sy = 0;
+                if (with_stale && g.stale) sy = (int)((reinterpret_cast<const unsigned long long *>(g.stale)[fr * (a.rh * CH) + j * CH + (n >> 6)] >> (n & 63)) & 1ull);
+                for (int e = a.row_start[j]; e < a.row_start[j + 1]; ++e) {
+                    const uint32_t d = a.edges[e];
+                    int i = n + (int)(d & 0xffffu);
+                    if (i >= M) i -= M;
+                    sy ^= (int)(w.soft[(int)(d >> 16) * M + i] < 0);
+                }
+                left[chk] = (uint8_t)sy;
+                fail |= sy;
+            }
+            return __syncthreads_or(fail);
+        };
+        for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {
+            const double y = maxd(mind(a.llr[fr * N + v], 20.0), -20.0);            // :1738 INPUT_LIMIT
+            yd[v] = w.soft[v] = y;
+        }
+        for (size_t i = threadIdx.x; i < (size_t)ne * M; i += (int)blockDim.x) ZZ[i] = 0.0;   // :1731-1733
+        __syncthreads();
+        int fail = syndrome(true);
+        // re-decode pass: nothing can change unless the frame was a codeword at its input (see bp_body)
+        if (g.frame_idx && fail && a.iters && a.iters[fr] != 0) { __syncthreads(); continue; }
+        int iter = 0;
+        while (fail && iter < a.maxiter) {
+            for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {                // A: variable-node activation :1803-1812
+                const int k = v / M, t = v - k * M;
+                const double so = w.soft[v];
+                for (int q = a.col_start[k]; q < a.col_start[k + 1]; ++q) {
+                    const size_t zi = (size_t)a.col_slot[q] * M + t;
+                    const double A = ldpc_spec::exp_glibc_wide(so - ZZ[zi], ldpc_spec::kExpTab);
+                    ZZ[zi] = ldpc_spec::log_glibc(fabs((A - 1) / (A + 1)));
+                    BB[zi] = A < 1;
+                }
+            }
+            __syncthreads();
+            for (int chk = threadIdx.x; chk < R; chk += (int)blockDim.x) {          // A': check sums :1815-1824, columns ascending
+                const int j = chk / M, n = chk - j * M;
+                double s = 0.0;
+                unsigned b = 0;
+                for (int e = a.row_start[j]; e < a.row_start[j + 1]; ++e) {
+                    int i = n + (int)(a.edges[e] & 0xffffu);
+                    if (i >= M) i -= M;
+                    s += ZZ[(size_t)e * M + i];
+                    b ^= BB[(size_t)e * M + i];
+                }
+                S[chk] = s;
+                bs[chk] = (uint8_t)b;
+            }
+            __syncthreads();
+            for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {                // B: check-node activation seen from the variable :1834-1866
+                const int k = v / M, t = v - k * M;
+                double soft = yd[v];
+                for (int q = a.col_start[k]; q < a.col_start[k + 1]; ++q) {         // rows ascending
+                    const uint32_t d = a.col_edges[q];
+                    const int j = (int)(d >> 16);
+                    int nn = t - (int)(d & 0xffffu);
+                    if (nn < 0) nn += M;
+                    const size_t zi = (size_t)a.col_slot[q] * M + t;
+                    double A = ldpc_spec::exp_glibc_wide(S[j * M + nn] - ZZ[zi], ldpc_spec::kExpTab);
+                    const int b = bs[j * M + nn] ^ BB[zi];
+                    A = (double)(1 - 2 * b) * ldpc_spec::log_glibc((1 + A) / (1 - A));
+                    const double zn = maxd(mind(A, 19.07), -19.07);
+                    ZZ[zi] = zn;
+                    soft += zn;
+                }
+                w.soft[v] = soft;
+            }
+            __syncthreads();
+            fail = syndrome(false);
+            iter = iter + 1;
+        }
+        if (g.synd_out) {
+            for (int u = threadIdx.x; u < a.rh * CH; u += (int)blockDim.x) {        // one u64 per block row and 64-lane chunk
+                const int j = u / CH, ch = u - j * CH;
+                unsigned long long bits = 0;
+                for (int l = 0; l < 64 && ch * 64 + l < M; ++l) bits |= (unsigned long long)left[j * M + ch * 64 + l] << l;
+                reinterpret_cast<unsigned long long *>(g.synd_out)[fr * (a.rh * CH) + u] = bits;
+            }
+        }
+        glob_outputs<0>(a, w, fr, fail ? -iter : iter);
         __syncthreads();
     }
 }

@@ -334,6 +334,57 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
     return p;
 }
 
+// BP_DEC frame chain (upstream's uncleared syndrome array, decoders.cpp:1742-1762).  Frames are decoded as if one after the
+// other on ONE upstream DEC_STATE: frame b's input check sees the syndrome frame b-1 left behind, frame 0 the one the previous
+// call left in this context.  A frame's final syndrome is non-zero exactly when it failed, and the stale syndrome only matters
+// to the input check, so: pass 1 with zero stale syndromes (frame 0: the carry); then re-decode only the frames that follow a
+// failed frame, with stale[b] = synd[b-1] (the kernel leaves at once when nothing can change), and repeat for successors of
+// frames whose outcome flipped.  Synchronises the stream (it reads the iteration counts back).
+// launch(frames, io) enqueues one pass of the decoder's kernel (resident or global tier) over `frames` workgroup slots.
+struct ChainIo { const uint32_t *stale = nullptr; uint32_t *synd_out = nullptr; const int *frame_idx = nullptr; int32_t *iters = nullptr; };
+template <class Launch>
+int run_bp_chain(ldpc_hip_ctx *c, long long B, int32_t *d_iters, hipStream_t stream, Launch launch) {
+    const size_t sw = (size_t)c->rh * ((c->M + 63) / 64) * 2;   // u32 words per frame: one u64 per block row and 64-lane chunk
+    if (B > c->bp_frames) {
+        if (c->d_bp_stale) (void)hipFree(c->d_bp_stale);
+        if (c->d_bp_synd) (void)hipFree(c->d_bp_synd);
+        if (c->d_bp_idx) (void)hipFree(c->d_bp_idx);
+        c->d_bp_stale = nullptr; c->d_bp_synd = nullptr; c->d_bp_idx = nullptr; c->bp_frames = 0;
+        HIP_TRY(hipMalloc(&c->d_bp_stale, sizeof(uint32_t) * sw * (size_t)B));
+        HIP_TRY(hipMalloc(&c->d_bp_synd, sizeof(uint32_t) * sw * (size_t)B));
+        HIP_TRY(hipMalloc(&c->d_bp_idx, sizeof(int32_t) * (size_t)B));
+        c->bp_frames = B;
+    }
+    int32_t *own_iters = nullptr;   // the chain needs the iteration counts even if the caller does not
+    if (!d_iters) HIP_TRY(hipMalloc(&own_iters, sizeof(int32_t) * (size_t)B));
+    std::unique_ptr<int32_t, void (*)(int32_t *)> own_guard(own_iters, [](int32_t *p) { if (p) (void)hipFree(p); });
+    ChainIo io;
+    io.iters = d_iters ? d_iters : own_iters;
+    HIP_TRY(hipMemsetAsync(c->d_bp_stale, 0, sizeof(uint32_t) * sw * (size_t)B, stream));
+    HIP_TRY(hipMemcpyAsync(c->d_bp_stale, c->bp_carry.data(), sizeof(uint32_t) * sw, hipMemcpyHostToDevice, stream));
+    io.stale = c->d_bp_stale; io.synd_out = c->d_bp_synd; io.frame_idx = nullptr;
+    if (int rc = launch(B, io)) return rc;
+    std::vector<int32_t> it_old((size_t)B), it_new((size_t)B), todo;
+    HIP_TRY(hipMemcpyAsync(it_old.data(), io.iters, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (long long b = 1; b < B; ++b) if (it_old[b - 1] < 0) todo.push_back((int32_t)b);
+    while (!todo.empty()) {
+        if (B > 1) HIP_TRY(hipMemcpyAsync(c->d_bp_stale + sw, c->d_bp_synd, sizeof(uint32_t) * sw * (size_t)(B - 1), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c->d_bp_idx, todo.data(), sizeof(int32_t) * todo.size(), hipMemcpyHostToDevice, stream));
+        io.frame_idx = c->d_bp_idx;
+        if (int rc = launch((long long)todo.size(), io)) return rc;
+        HIP_TRY(hipMemcpyAsync(it_new.data(), io.iters, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        std::vector<int32_t> next;
+        for (int32_t b : todo)
+            if ((it_old[b] < 0) != (it_new[b] < 0) && b + 1 < B) next.push_back(b + 1);  // its successor saw the wrong stale syndrome
+        it_old = it_new;
+        todo.swap(next);
+    }
+    HIP_TRY(hipMemcpy(c->bp_carry.data(), c->d_bp_synd + sw * (size_t)(B - 1), sizeof(uint32_t) * sw, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -426,14 +477,16 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
         }
     }
     const char *genv = getenv("LDPC_HIP_FORCE_GLOBAL");   // tests: run the shape-unlimited tier on shapes the resident kernels take
-    const bool can_global = decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || decoder_id == LDPC_HIP_SP_DEC || decoder_id == LDPC_HIP_IMS_DEC ||
-                            (decoder_id == LDPC_HIP_TASP_DEC && t.min_rw >= 2);
+    bool all_cw2 = true;   // upstream's all-columns-of-weight-2 branch of decoder 2 (decoders.cpp:2431-2480) is not built
+    for (int k = 0; k < nh; ++k) all_cw2 = all_cw2 && (t.col_start[k + 1] - t.col_start[k] == 2);
+    const bool can_global = decoder_id == LDPC_HIP_BP_DEC || decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || decoder_id == LDPC_HIP_SP_DEC || decoder_id == LDPC_HIP_IMS_DEC ||
+                            (decoder_id == LDPC_HIP_TASP_DEC && t.min_rw >= 2) || (decoder_id == LDPC_HIP_ASP_DEC && t.min_rw >= 2 && !all_cw2);
     if (can_global && ((genv && atoi(genv) != 0) || (!c->spec_aot && !c->spec_jit && !have_generic))) {
         c->global_tier = true;
         c->spec_aot = nullptr; c->spec_jit = nullptr;
-        c->kernel_name = decoder_id == LDPC_HIP_MS_DEC ? "ms_global_kernel" : decoder_id == LDPC_HIP_LMS_DEC ? "lms_global_kernel" : decoder_id == LDPC_HIP_IMS_DEC ? "ims_global_kernel" :
+        c->kernel_name = decoder_id == LDPC_HIP_MS_DEC ? "ms_global_kernel" : decoder_id == LDPC_HIP_LMS_DEC ? "lms_global_kernel" : decoder_id == LDPC_HIP_IMS_DEC ? "ims_global_kernel" : decoder_id == LDPC_HIP_ASP_DEC ? "asp_global_kernel" : decoder_id == LDPC_HIP_BP_DEC ? "bp_global_kernel" :
                          decoder_id == LDPC_HIP_SP_DEC ? "sp_global_kernel" : "tasp_global_kernel";
-        c->glob_stride = ldpc::glob_ws_bytes(c->N, c->R, t.ne, M, (decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_IMS_DEC) ? 0 : decoder_id == LDPC_HIP_TASP_DEC ? 4 : 1);
+        c->glob_stride = ldpc::glob_ws_bytes(c->N, c->R, t.ne, M, (decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_IMS_DEC) ? 0 : decoder_id == LDPC_HIP_TASP_DEC ? 4 : decoder_id == LDPC_HIP_ASP_DEC ? 3 : 1);
     }
     if (decoder_id == LDPC_HIP_IMS_DEC && !c->global_tier)   // parameters beyond int8 may send a launch to the global tier later
         c->glob_stride = ldpc::glob_ws_bytes(c->N, c->R, t.ne, M, 0);
@@ -441,7 +494,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
         if (!have_generic)
             return fail(LDPC_HIP_EUNSUPPORTED, "decoder %d, code %dx%d lifting %d: not supported by the generic kernel (limits: %d block rows, "
                         "%d block columns, row weight %d, M <= 512, 160 KiB LDS), no code-specialised instance: %s; the shape-unlimited "
-                        "tier serves sum-product (1), min-sum (3), integer min-sum (4), TDMP sum-product (7) and layered min-sum (8) only",
+                        "tier serves every built decoder; decoders 2 and 7 need row weights >= 2, decoder 2 a block column of weight != 2",
                         decoder_id, rh, nh, M, kRHM, kNHM, kRWM, why_not.c_str());
         if (plan.body && c->variant >= 2)
             fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", why_not.c_str(), c->kernel_name.c_str());
@@ -551,11 +604,29 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
             ga.ims_coef = c->d_ims_coef;
             ga.d.ims_thr = c->ims_thr; ga.d.ims_qbits = c->ims_qbits; ga.d.ims_dbits = c->ims_dbits;
         }
-        if (c->decoder_id == LDPC_HIP_MS_DEC) hipLaunchKernelGGL(ldpc::ms_global_kernel, dim3((unsigned)grid), dim3((unsigned)ldpc::glob_threads(c->N)), 0, stream, ga);
-        else if (c->decoder_id == LDPC_HIP_LMS_DEC) hipLaunchKernelGGL(ldpc::lms_global_kernel, dim3((unsigned)grid), dim3((unsigned)ldpc::glob_threads(c->N)), 0, stream, ga);
-        else if (c->decoder_id == LDPC_HIP_IMS_DEC) hipLaunchKernelGGL(ldpc::ims_global_kernel, dim3((unsigned)grid), dim3((unsigned)ldpc::glob_threads(c->N)), 0, stream, ga);
-        else if (c->decoder_id == LDPC_HIP_SP_DEC) hipLaunchKernelGGL(ldpc::sp_global_kernel, dim3((unsigned)grid), dim3((unsigned)ldpc::glob_threads(c->N)), 0, stream, ga);
-        else hipLaunchKernelGGL(ldpc::tasp_global_kernel, dim3((unsigned)grid), dim3((unsigned)ldpc::glob_threads(c->N)), 0, stream, ga);
+        auto glaunch = [&](long long slots, const ChainIo &io) -> int {
+            ga.slots = slots; ga.stale = io.stale; ga.synd_out = io.synd_out; ga.frame_idx = io.frame_idx;
+            if (io.iters) ga.d.iters = io.iters;
+            const dim3 gg((unsigned)(slots < grid ? slots : grid)), bb((unsigned)ldpc::glob_threads(c->N));
+            switch (c->decoder_id) {
+            case LDPC_HIP_MS_DEC: hipLaunchKernelGGL(ldpc::ms_global_kernel, gg, bb, 0, stream, ga); break;
+            case LDPC_HIP_LMS_DEC: hipLaunchKernelGGL(ldpc::lms_global_kernel, gg, bb, 0, stream, ga); break;
+            case LDPC_HIP_IMS_DEC: hipLaunchKernelGGL(ldpc::ims_global_kernel, gg, bb, 0, stream, ga); break;
+            case LDPC_HIP_ASP_DEC: hipLaunchKernelGGL(ldpc::asp_global_kernel, gg, bb, 0, stream, ga); break;
+            case LDPC_HIP_SP_DEC: hipLaunchKernelGGL(ldpc::sp_global_kernel, gg, bb, 0, stream, ga); break;
+            case LDPC_HIP_BP_DEC: hipLaunchKernelGGL(ldpc::bp_global_kernel, gg, bb, 0, stream, ga); break;
+            default: hipLaunchKernelGGL(ldpc::tasp_global_kernel, gg, bb, 0, stream, ga); break;
+            }
+            HIP_TRY(hipGetLastError());
+            return 0;
+        };
+        if (c->decoder_id == LDPC_HIP_BP_DEC && c->bp_chain) {
+            if (int rc = run_bp_chain(c, B, d_iters, stream, glaunch)) return rc;
+        } else {
+            ChainIo io;
+            io.iters = d_iters;
+            if (int rc = glaunch(B, io)) return rc;
+        }
     } else if (use_spec) {
         // code-specialised kernel: one frame per workgroup
         ldpc_spec::SpecArgs sa{};
@@ -587,48 +658,11 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
             return 0;
         };
         if (c->decoder_id == LDPC_HIP_BP_DEC && c->bp_chain) {
-            // Frames are decoded as if one after the other on ONE upstream DEC_STATE: frame b's input check sees the
-            // syndrome frame b-1 left behind, frame 0 the one the previous call left in this context.  A frame's final
-            // syndrome is non-zero exactly when it failed, and the stale syndrome only matters to the input check, so:
-            // pass 1 with zero stale syndromes (frame 0: the carry); then re-decode only the frames that follow a
-            // failed frame, with stale[b] = synd[b-1], and repeat for successors of frames whose outcome flipped.
-            // This entry point therefore synchronises the stream for BP_DEC (it reads the iteration counts back).
-            const size_t sw = (size_t)c->rh * ((c->M + 63) / 64) * 2;   // u32 words per frame: one u64 per block row and 64-lane chunk
-            if (B > c->bp_frames) {
-                if (c->d_bp_stale) (void)hipFree(c->d_bp_stale);
-                if (c->d_bp_synd) (void)hipFree(c->d_bp_synd);
-                if (c->d_bp_idx) (void)hipFree(c->d_bp_idx);
-                c->d_bp_stale = nullptr; c->d_bp_synd = nullptr; c->d_bp_idx = nullptr; c->bp_frames = 0;
-                HIP_TRY(hipMalloc(&c->d_bp_stale, sizeof(uint32_t) * sw * (size_t)B));
-                HIP_TRY(hipMalloc(&c->d_bp_synd, sizeof(uint32_t) * sw * (size_t)B));
-                HIP_TRY(hipMalloc(&c->d_bp_idx, sizeof(int32_t) * (size_t)B));
-                c->bp_frames = B;
-            }
-            int32_t *own_iters = nullptr;   // the chain needs the iteration counts even if the caller does not
-            if (!d_iters) { HIP_TRY(hipMalloc(&own_iters, sizeof(int32_t) * (size_t)B)); sa.iters = own_iters; }
-            std::unique_ptr<int32_t, void (*)(int32_t *)> own_guard(own_iters, [](int32_t *p) { if (p) (void)hipFree(p); });
-            HIP_TRY(hipMemsetAsync(c->d_bp_stale, 0, sizeof(uint32_t) * sw * (size_t)B, stream));
-            HIP_TRY(hipMemcpyAsync(c->d_bp_stale, c->bp_carry.data(), sizeof(uint32_t) * sw, hipMemcpyHostToDevice, stream));
-            sa.stale = c->d_bp_stale; sa.synd_out = c->d_bp_synd; sa.frame_idx = nullptr;
-            if (int rc = launch(B)) return rc;
-            std::vector<int32_t> it_old((size_t)B), it_new((size_t)B), todo;
-            HIP_TRY(hipMemcpyAsync(it_old.data(), sa.iters, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            for (long long b = 1; b < B; ++b) if (it_old[b - 1] < 0) todo.push_back((int32_t)b);
-            while (!todo.empty()) {
-                if (B > 1) HIP_TRY(hipMemcpyAsync(c->d_bp_stale + sw, c->d_bp_synd, sizeof(uint32_t) * sw * (size_t)(B - 1), hipMemcpyDeviceToDevice, stream));
-                HIP_TRY(hipMemcpyAsync(c->d_bp_idx, todo.data(), sizeof(int32_t) * todo.size(), hipMemcpyHostToDevice, stream));
-                sa.frame_idx = c->d_bp_idx;
-                if (int rc = launch((long long)todo.size())) return rc;
-                HIP_TRY(hipMemcpyAsync(it_new.data(), sa.iters, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
-                std::vector<int32_t> next;
-                for (int32_t b : todo)
-                    if ((it_old[b] < 0) != (it_new[b] < 0) && b + 1 < B) next.push_back(b + 1);  // its successor saw the wrong stale syndrome
-                it_old = it_new;
-                todo.swap(next);
-            }
-            HIP_TRY(hipMemcpy(c->bp_carry.data(), c->d_bp_synd + sw * (size_t)(B - 1), sizeof(uint32_t) * sw, hipMemcpyDeviceToHost));
+            if (int rc = run_bp_chain(c, B, d_iters, stream, [&](long long frames, const ChainIo &io) -> int {
+                    sa.stale = io.stale; sa.synd_out = io.synd_out; sa.frame_idx = io.frame_idx; sa.iters = io.iters;
+                    return launch(frames);
+                }))
+                return rc;
         } else {
             if (int rc = launch(B)) return rc;
         }
