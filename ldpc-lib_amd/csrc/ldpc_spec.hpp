@@ -119,7 +119,7 @@ struct FrameVote {
 // evaluation order of the FMA build that x86-64 hosts with FMA select at run time: then the a-posteriori values of SP / ASP /
 // TDMP are IDENTICAL to the CPU reference's, not merely close.  (tools/gen_exp_table.py computes the table;
 // tests/test_host_cpu.py checks a C transcription against libm's exp() bit for bit.)  Valid for |x| < 700; callers clamp to 20.
-__device__ const unsigned long long kExpTab[256] = {
+__device__ alignas(16) const unsigned long long kExpTab[256] = {
     0x0000000000000000ull, 0x3ff0000000000000ull, 0x3c9b3b4f1a88bf6eull, 0x3feff63da9fb3335ull,
     0xbc7160139cd8dc5dull, 0x3fefec9a3e778061ull, 0xbc905e7a108766d1ull, 0x3fefe315e86e7f85ull,
     0x3c8cd2523567f613ull, 0x3fefd9b0d3158574ull, 0xbc8bce8023f98efaull, 0x3fefd06b29ddf6deull,
@@ -195,8 +195,9 @@ __device__ __forceinline__ double exp_glibc_t(double x, Tab T) {
     kd -= Shift;
     const double r = __fma_rn(kd, NegLn2loN, __fma_rn(kd, NegLn2hiN, x));   // x - k ln2/N
     const unsigned long long idx = 2 * (ki % 128);
-    const double tail = __longlong_as_double((long long)T[idx]);
-    const unsigned long long sbits = T[idx + 1] + (ki << (52 - 7));
+    const ulonglong2 pair = *reinterpret_cast<const ulonglong2 *>(&T[idx]);   // (tail, sbits) sit side by side, 16-byte aligned: one load
+    const double tail = __longlong_as_double((long long)pair.x);
+    const unsigned long long sbits = pair.y + (ki << (52 - 7));
     const double r2 = r * r;
     const double tmp = __fma_rn(r2 * r2, __fma_rn(r, C5, C4), __fma_rn(r2, __fma_rn(r, C3, C2), tail + r));
     const double scale = __longlong_as_double((long long)sbits);
@@ -209,7 +210,7 @@ __device__ __forceinline__ double exp_glibc(double x) { return exp_glibc_t(x, kE
 // order of the FMA build x86-64 hosts with FMA select at run time -- read off that build's instruction sequence.  kLogData is
 // printed by tools/gen_log_table.py: [0] ln2hi [1] ln2lo [2..6] A [7..17] B [18 + 2i] invc_i [19 + 2i] logc_i.
 // tests/test_host_cpu.py checks a C transcription against libm's log() bit for bit, all special cases included.
-__device__ const unsigned long long kLogData[274] = {
+__device__ alignas(16) const unsigned long long kLogData[274] = {
     0x3fe62e42fefa3800ull, 0x3d2ef35793c76730ull, 0xbfe0000000000001ull, 0x3fd555555551305bull,
     0xbfcfffffffeb4590ull, 0x3fc999b324f10111ull, 0xbfc55575e506c89full, 0xbfe0000000000000ull,
     0x3fd5555555555577ull, 0xbfcffffffffffdcbull, 0x3fc999999995dd0cull, 0xbfc55555556745a7ull,
@@ -311,7 +312,8 @@ __device__ __forceinline__ double log_glibc_t(double x, Tab T) {
     const int i = (int)((tmp >> (52 - 7)) % 128);
     const long long k = (long long)tmp >> 52;
     const unsigned long long iz = ix - (tmp & (0xfffull << 52));
-    const double invc = D(18 + 2 * i), logc = D(19 + 2 * i), z = __longlong_as_double((long long)iz);
+    const ulonglong2 cpair = *reinterpret_cast<const ulonglong2 *>(&T[18 + 2 * i]);   // (invc, logc): one 16-byte load
+    const double invc = __longlong_as_double((long long)cpair.x), logc = __longlong_as_double((long long)cpair.y), z = __longlong_as_double((long long)iz);
     const double r = __fma_rn(z, invc, -1.0);
     const double kd = (double)k;
     const double w = __fma_rn(kd, D(0), logc);

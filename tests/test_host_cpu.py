@@ -334,9 +334,9 @@ def test_device_exp_algorithm_equals_libm_exp_bit_for_bit(tmp_path):
     fn = hdr[hdr.index("__device__ __forceinline__ double exp_glibc_t(double x, Tab T) {"):]
     fn = fn[:fn.index("\n}\n") + 3]
     c_fn = (fn.replace("__device__ __forceinline__ double exp_glibc_t(double x, Tab T)", "static double exp_glibc(double x)").replace("__fma_rn", "fma")
-              .replace("T[idx + 1]", "kExpTab[idx + 1]").replace("T[idx]", "kExpTab[idx]")
+              .replace("const ulonglong2 pair = *reinterpret_cast<const ulonglong2 *>(&T[idx]);", "const struct { unsigned long long x, y; } pair = {kExpTab[idx], kExpTab[idx + 1]};")
               .replace("(unsigned long long)__double_as_longlong(kd)", "asu(kd)")
-              .replace("__longlong_as_double((long long)kExpTab[idx])", "asd(kExpTab[idx])")
+              .replace("__longlong_as_double((long long)pair.x)", "asd(pair.x)")
               .replace("__longlong_as_double((long long)sbits)", "asd(sbits)"))
     src = ("#include <math.h>\n#include <stdint.h>\n#include <stdio.h>\n#include <string.h>\n"
            "static unsigned long long asu(double x){unsigned long long u;memcpy(&u,&x,8);return u;}\n"
@@ -370,6 +370,8 @@ def test_device_log_algorithm_equals_libm_log_bit_for_bit(tmp_path):
     fn = fn[:fn.index("\n}\n") + 3]
     c_fn = (fn.replace("__device__ __forceinline__ double log_glibc_t(double x, Tab T)", "static double log_glibc(double x)").replace("__fma_rn", "fma")
               .replace("    auto D = [&](int i) { return __longlong_as_double((long long)T[i]); };\n", "")
+              .replace("const ulonglong2 cpair = *reinterpret_cast<const ulonglong2 *>(&T[18 + 2 * i]);", "const struct { unsigned long long x, y; } cpair = {kLogData[18 + 2 * i], kLogData[19 + 2 * i]};")
+              .replace("__longlong_as_double((long long)cpair.x)", "asd(cpair.x)").replace("__longlong_as_double((long long)cpair.y)", "asd(cpair.y)")
               .replace("(unsigned long long)__double_as_longlong(", "asu(").replace("__longlong_as_double((long long)iz)", "asd(iz)")
               .replace("__longlong_as_double(0x7ff0000000000000ll)", "asd(0x7ff0000000000000ull)")
               .replace("__longlong_as_double(0x7ff8000000000000ll)", "asd(0x7ff8000000000000ull)")

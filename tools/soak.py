@@ -21,7 +21,7 @@ FAMILY = (SP_DEC, ASP_DEC, TASP_DEC, BP_DEC) if "--sp" in sys.argv else (MS_DEC,
 GLOBAL = "--global" in sys.argv     # the shape-unlimited tier (ldpc_global.hpp) forced on: no hiprtc, larger shapes too
 if GLOBAL:
     os.environ["LDPC_HIP_FORCE_GLOBAL"] = "1"
-    FAMILY = (MS_DEC, LMS_DEC, SP_DEC, TASP_DEC)
+    FAMILY = (MS_DEC, LMS_DEC, SP_DEC, TASP_DEC, IMS_DEC, ASP_DEC, BP_DEC)
 if "--only" in sys.argv:
     FAMILY = (int(sys.argv[sys.argv.index("--only") + 1]),)
 TOL = {}   # every decoder bit for bit: exp() / log() are glibc's algorithms on the device
