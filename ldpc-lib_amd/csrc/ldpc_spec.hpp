@@ -119,7 +119,7 @@ struct FrameVote {
 // evaluation order of the FMA build that x86-64 hosts with FMA select at run time: then the a-posteriori values of SP / ASP /
 // TDMP are IDENTICAL to the CPU reference's, not merely close.  (tools/gen_exp_table.py computes the table;
 // tests/test_host_cpu.py checks a C transcription against libm's exp() bit for bit.)  Valid for |x| < 700; callers clamp to 20.
-__device__ alignas(16) const unsigned long long kExpTab[256] = {
+__device__ __attribute__((aligned(16))) const unsigned long long kExpTab[256] = {
     0x0000000000000000ull, 0x3ff0000000000000ull, 0x3c9b3b4f1a88bf6eull, 0x3feff63da9fb3335ull,
     0xbc7160139cd8dc5dull, 0x3fefec9a3e778061ull, 0xbc905e7a108766d1ull, 0x3fefe315e86e7f85ull,
     0x3c8cd2523567f613ull, 0x3fefd9b0d3158574ull, 0xbc8bce8023f98efaull, 0x3fefd06b29ddf6deull,
@@ -210,7 +210,7 @@ __device__ __forceinline__ double exp_glibc(double x) { return exp_glibc_t(x, kE
 // order of the FMA build x86-64 hosts with FMA select at run time -- read off that build's instruction sequence.  kLogData is
 // printed by tools/gen_log_table.py: [0] ln2hi [1] ln2lo [2..6] A [7..17] B [18 + 2i] invc_i [19 + 2i] logc_i.
 // tests/test_host_cpu.py checks a C transcription against libm's log() bit for bit, all special cases included.
-__device__ alignas(16) const unsigned long long kLogData[274] = {
+__device__ __attribute__((aligned(16))) const unsigned long long kLogData[274] = {
     0x3fe62e42fefa3800ull, 0x3d2ef35793c76730ull, 0xbfe0000000000001ull, 0x3fd555555551305bull,
     0xbfcfffffffeb4590ull, 0x3fc999b324f10111ull, 0xbfc55575e506c89full, 0xbfe0000000000000ull,
     0x3fd5555555555577ull, 0xbfcffffffffffdcbull, 0x3fc999999995dd0cull, 0xbfc55555556745a7ull,
