@@ -68,8 +68,8 @@ LDPC_AOT_KERNEL(ims_spec_appendix_c_m64_kernel, ims_body, CodeAppendixCM64, 64, 
 LDPC_AOT_KERNEL(ims_spec_appendix_c_m126_kernel, ims_body, CodeAppendixCM126, 128, 2)
 LDPC_AOT_KERNEL(lms_spec_appendix_c_m64_kernel, lms_body, CodeAppendixCM64, 64, 2)
 LDPC_AOT_KERNEL(lms_spec_appendix_c_m512_kernel, lms_body, CodeAppendixCM512, 512, 2)
-// two frames per CU (<= 128 VGPRs, a few spills) beats one frame with 243 VGPRs: 4.18 vs 3.70 M frames/s at 2 dB
-LDPC_AOT_KERNEL(sp_spec_appendix_c_m64_kernel, sp_body, CodeAppendixCM64, 512, 4)
+// asp / bp: two frames per CU (<= 128 VGPRs, some spills) beats one frame with 243 VGPRs; sp: four waves per frame (below)
+LDPC_AOT_KERNEL(sp_spec_appendix_c_m64_kernel, sp_body, CodeAppendixCM64, 256, 2)   // four waves per frame, two frames per CU (ldpc_spec::kSpBodyWaves)
 LDPC_AOT_KERNEL(bp_spec_appendix_c_m64_kernel, bp_body, CodeAppendixCM64, 512, 4)
 LDPC_AOT_KERNEL(asp_spec_appendix_c_m64_kernel, asp_body, CodeAppendixCM64, 512, 4)
 LDPC_AOT_KERNEL(tasp_spec_appendix_c_m64_kernel, tasp_body, CodeAppendixCM64, 64, 1)
@@ -150,7 +150,7 @@ const AotInstance kAot[] = {
     {LDPC_HIP_IMS_DEC, (const void *)ims_spec_appendix_c_m126_kernel, 128, "ims_spec_appendix_c_m126_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM126>},
     {LDPC_HIP_LMS_DEC, (const void *)lms_spec_appendix_c_m64_kernel, 64, "lms_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_LMS_DEC, (const void *)lms_spec_appendix_c_m512_kernel, 512, "lms_spec_appendix_c_m512_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM512>},
-    {LDPC_HIP_SP_DEC, (const void *)sp_spec_appendix_c_m64_kernel, 512, "sp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
+    {LDPC_HIP_SP_DEC, (const void *)sp_spec_appendix_c_m64_kernel, 256, "sp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_BP_DEC, (const void *)bp_spec_appendix_c_m64_kernel, 512, "bp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_ASP_DEC, (const void *)asp_spec_appendix_c_m64_kernel, 512, "asp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_TASP_DEC, (const void *)tasp_spec_appendix_c_m64_kernel, 64, "tasp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
@@ -307,7 +307,7 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
     }
     case LDPC_HIP_SP_DEC: {
         const size_t lds = ldpc::sp_lds_bytes(t.ne, M, t.rh * M, N);
-        if (M >= 33 && lds <= 160 * 1024) { p.body = "sp_body"; p.threads = 512; p.lds = lds; }
+        if (M >= 33 && lds <= 160 * 1024) { p.body = "sp_body"; p.threads = 64 * ldpc_spec::kSpBodyWaves; p.lds = lds; }
         break;
     }
     case LDPC_HIP_BP_DEC: {

@@ -1221,9 +1221,17 @@ __device__ __forceinline__ void lms_small_body(const SpecArgs &a) {
 // other operation is exact and in the reference's order: hard decisions, iteration counts AND the a-posteriori ratios are
 // identical to the CPU reference's.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kSpWaves = 8;
+#ifndef LDPC_SP_WAVES
+#define LDPC_SP_WAVES 8           // (macros: tools/ab_sp.hip builds the variants)
+#endif
+#ifndef LDPC_SP_BODY_WAVES
+#define LDPC_SP_BODY_WAVES 4
+#endif
+constexpr int kSpWaves = LDPC_SP_WAVES;       // wavefronts per frame of the asp / bp bodies (two frames per CU at 4 waves per SIMD, <= 128 VGPRs)
+constexpr int kSpBodyWaves = LDPC_SP_BODY_WAVES;   // sp_body: four waves per frame at 2 waves per SIMD (256 VGPRs, no spills) is 9-13 % faster than eight with
+                                  // 101 spilled registers (tools/ab_sp.hip, profiles/r02_sp_variants.txt); asp_body gains nothing, bp_body loses 25 %
 
-template <class C>
+template <class C, int WAVES = kSpWaves>
 struct SpView {  // column view of the code + static work split, all computed at compile time
     static constexpr int CH = (C::M + 63) / 64;          // 64-lane chunks per circulant (the last one may be partly idle)
     int row_off[C::RH + 1] = {};                         // row-major edge id of (row j, slot 0)
@@ -1244,24 +1252,24 @@ struct SpView {  // column view of the code + static work split, all computed at
                 ce[k][cw[k]] = row_off[j] + s; cj[k][cw[k]] = j; cc[k][cw[k]] = C::SH[j][s];
                 ++cw[k];
             }
-        int load[kSpWaves] = {}, cnt[kSpWaves] = {};
+        int load[WAVES] = {}, cnt[WAVES] = {};
         bool used[C::NH * ((C::M + 63) / 64)] = {};
         for (int it = 0; it < C::NH * CH; ++it) {         // heaviest remaining unit -> least loaded wave
             int best = -1;
             for (int u = 0; u < C::NH * CH; ++u)
                 if (!used[u] && (best < 0 || cw[u / CH] > cw[best / CH])) best = u;
             int w = 0;
-            for (int x = 1; x < kSpWaves; ++x) if (load[x] < load[w]) w = x;
+            for (int x = 1; x < WAVES; ++x) if (load[x] < load[w]) w = x;
             used[best] = true; col_wave[best] = w; col_slot[best] = cnt[w]++; load[w] += cw[best / CH];
         }
-        for (int x = 0; x < kSpWaves; ++x) if (cnt[x] > units_max) units_max = cnt[x];
+        for (int x = 0; x < WAVES; ++x) if (cnt[x] > units_max) units_max = cnt[x];
     }
 };
 
 template <class C>
 __device__ __forceinline__ void sp_body(const SpecArgs &a) {
-    constexpr SpView<C> V{};
-    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, R = RH * M, CH = (M + 63) / 64, T = kSpWaves * 64;
+    constexpr SpView<C, kSpBodyWaves> V{};
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, R = RH * M, CH = (M + 63) / 64, T = kSpBodyWaves * 64;
     constexpr int NE = V.ne, UMAX = V.units_max;
     extern __shared__ double lds[];
     char *const zzb = reinterpret_cast<char *>(lds);                        // ZZ[e][t] at e*M*8 + t*8
@@ -1277,12 +1285,12 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
     FrameVote fvote;
     fvote.init(flag);
     auto vote = [&](bool fail) -> bool { return fvote(fail); };
-    // rows (x chunks) are dealt round-robin to the waves: unit (j, ch) -> wave (j*CH + ch) % 8
+    // rows (x chunks) are dealt round-robin to the waves: unit (j, ch) -> wave (j*CH + ch) % kSpBodyWaves
     auto syndrome_fail = [&]() -> bool {
         bool f = false;
         static_for<0, RH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
-            if (wave == u % kSpWaves && lane_ok(IC<ch>{})) {
+            if (wave == u % kSpBodyWaves && lane_ok(IC<ch>{})) {
                 const int n = ch * 64 + lane;
                 unsigned sy = 0;
                 static_for<0, C::RW[j]>([&](auto S) {
@@ -1340,7 +1348,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
         // ---- phase B
         static_for<0, RH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
-            if (wave == u % kSpWaves && lane_ok(IC<ch>{})) {
+            if (wave == u % kSpBodyWaves && lane_ok(IC<ch>{})) {
                 const int n = ch * 64 + lane;
                 double s = 1.0;                                                       // :2010
                 static_for<0, C::RW[j]>([&](auto S) {
