@@ -406,6 +406,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
         decoder_id != LDPC_HIP_TASP_DEC && decoder_id != LDPC_HIP_ASP_DEC && decoder_id != LDPC_HIP_BP_DEC)
         return fail(LDPC_HIP_EUNSUPPORTED, "ldpc_hip_open: decoder id %d is not built (built: BP=0, SP=1, ASP=2, MS=3, IMS=4, TASP=7, LMS=8)", decoder_id);
     if (M >= 65536 || nh >= 65536 || rh >= 65536) return fail(LDPC_HIP_EUNSUPPORTED, "M, rh and nh must be < 65536");
+    if ((long long)nh * M >= (1LL << 28)) return fail(LDPC_HIP_EUNSUPPORTED, "code length nh * M = %lld: at most 2^28 - 1 is supported (32-bit indices)", (long long)nh * M);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(LDPC_HIP_EINVAL, "ldpc_hip_open: device %d of %d", device, ndev);
@@ -1000,7 +1001,9 @@ namespace {
 // ordered per-frame records when not null.  Asynchronous except for BP_DEC with the chain on.
 int sim_enqueue(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha, uint64_t seed,
                 long long first_frame, long long B, int32_t *d_frame_info, int32_t *d_iters_out, hipStream_t stream) {
-    const long long chunk_max = 1 << 16;
+    // frames per pass: at most 65536, and at most 8 GiB of LLRs (very long codes on the shape-unlimited tier)
+    long long chunk_max = ((long long)8 << 30) / ((long long)sizeof(double) * c->N);
+    chunk_max = chunk_max > (1 << 16) ? (1 << 16) : (chunk_max < 64 ? 64 : chunk_max);
     const long long chunk = B < chunk_max ? B : chunk_max;
     if (chunk > 0) { if (int rc = ensure_workspace(c, chunk, false)) return rc; }
     for (long long done = 0; done < B; done += chunk) {
