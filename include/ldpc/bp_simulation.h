@@ -1,10 +1,12 @@
 /*
  * ldpc/bp_simulation.h -- the Monte-Carlo harness of upstream's bp_simulation.h:9-27 / bp_simulation.cpp:305-841
- * on the MI355X batch decoder, in EXACT-REPLAY mode: the channel noise comes from the same std::mt19937 in the same
- * draw order as upstream (commons_portable.cpp:138-178, bp_simulation.cpp:512,600-611), frames are decoded in
- * GPU batches, and upstream's sequential stopping rule (bp_simulation.cpp:591,820) is replayed over the ordered
- * per-frame results.  On an early stop the generator is rolled back and re-advanced so that it is left exactly where
- * upstream's frame-by-frame loop leaves it (later callers draw from it: main_good_code_search.cpp:316).
+ * on the MI355X batch decoder, in EXACT-REPLAY mode: the channel noise is the stream of the same std::mt19937 in the same
+ * draw order as upstream (commons_portable.cpp:138-178, bp_simulation.cpp:512,600-611) -- continued ON THE GPU by default
+ * (ldpc_hip_mt_*: the generator's words, libstdc++'s polar method and glibc's log reproduced bit for bit, so only the 8-byte frame
+ * records cross PCIe; LDPC_HIP_EXACT_NOISE=host draws on the host instead) -- frames are decoded in GPU batches, and upstream's
+ * sequential stopping rule (bp_simulation.cpp:591,820) is replayed over the ordered per-frame results.  On an early stop the
+ * generator is rolled back and re-advanced so that it is left exactly where upstream's frame-by-frame loop leaves it (later
+ * callers draw from it: main_good_code_search.cpp:316).
  * Result, counters and generator state are identical to upstream's for q_mod == 2, modulation SKIP/QAM4,
  * permutation_type 0 (the only mode the shipped configurations use, files/default_constants.jsonx:6).
  *
@@ -26,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <sstream>
 #include <string>
 #include <utility>
 #include <vector>
@@ -90,6 +93,45 @@ struct OwnRngEnv {
     [[noreturn]] static void fail(const char *msg) { fprintf(stderr, "%s\n", msg); exit(1); }  // die()
 };
 
+// std::mt19937 <-> (624 state words, index of the next word): libstdc++ streams exactly that (bits/random.tcc operator<<).  The
+// export is checked against the generator's own next output; any other standard library fails the check and the harness then
+// keeps the noise on the host.
+inline unsigned mt_word_after(const uint32_t *w, int pos) {
+    unsigned y;
+    if (pos < 624) y = w[pos];
+    else {   // the block is used up: the next word is x[624] of the sequence that starts with these 624 words
+        const unsigned t = (w[0] & 0x80000000u) | (w[1] & 0x7fffffffu);
+        y = w[397] ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
+    }
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+inline bool mt_export(const std::mt19937 &g, uint32_t w[624], int &pos) {
+    std::ostringstream os;
+    os << g;
+    std::istringstream is(os.str());
+    for (int i = 0; i < 624; ++i) { unsigned long v = 0; is >> v; w[i] = (uint32_t)v; }
+    long p = -1;
+    is >> p;
+    if (is.fail() || p < 0 || p > 624) return false;
+    pos = (int)p;
+    std::mt19937 probe = g;
+    return (unsigned)probe() == mt_word_after(w, pos);
+}
+inline bool mt_import(std::mt19937 &g, const uint32_t w[624], int pos) {
+    std::ostringstream os;
+    for (int i = 0; i < 624; ++i) os << w[i] << ' ';
+    os << pos;
+    std::istringstream is(os.str());
+    std::mt19937 t;
+    is >> t;
+    if (is.fail()) return false;
+    std::mt19937 probe = t;
+    if ((unsigned)probe() != mt_word_after(w, pos)) return false;
+    g = t;
+    return true;
+}
+
 struct SimCounters { long long nse = 0, nde = 0, nue = 0, experiment = 0, sum_abs_iters = 0; };
 
 template <class Mat, class Env>
@@ -144,7 +186,53 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
     std::vector<int32_t> iters;
     long long batch = 64;
     bool stop = false;
-    while (!stop && nde < n_frame_errors && experiment <= n_experiments) {                      // :591
+
+    // Noise on the device (default): the GPUs continue the generator's own stream -- same words, same polar-method attempts, same
+    // libm log -- so nothing but the 8-byte frame records crosses PCIe.  LDPC_HIP_EXACT_NOISE=host keeps the draws on the host.
+    uint32_t mt_words[624];
+    int mt_pos = 0;
+    const char *noise_env = getenv("LDPC_HIP_EXACT_NOISE");
+    bool device_noise = !(noise_env && std::string(noise_env) == "host") && mt_export(Env::generator(), mt_words, mt_pos);
+    if (device_noise) {
+        if (ldpc_hip_multi_set_interleaver(ctx, permutation_type, permutation_block, permutation_inter) != 0) Env::fail(ldpc_hip_last_error());
+        if (ldpc_hip_mt_set_state_multi(ctx, mt_words, mt_pos) != 0) Env::fail(ldpc_hip_last_error());
+        const long long cap = (max_batch > 32768 * (long long)devices.size()) ? max_batch : 32768 * (long long)devices.size();
+        std::vector<int32_t> info;
+        batch = 256;
+        while (!stop && nde < n_frame_errors && experiment <= n_experiments) {                  // :591
+            const long long room = (long long)n_experiments + 1 - experiment;
+            const long long B = batch < room ? batch : room;
+            info.resize((size_t)B); iters.resize((size_t)B);
+            if (ldpc_hip_mt_get_state_multi(ctx, mt_words, &mt_pos) != 0) Env::fail(ldpc_hip_last_error());   // snapshot
+            if (ldpc_hip_mt_frames_multi(ctx, snr, modulation_type, punctured_blocks, max_iterations, 0.8 /*MS_ALPHA*/, B, info.data(),
+                                         iters.data()) != 0)
+                Env::fail(ldpc_hip_last_error());
+            long long used = 0;
+            for (long long f = 0; f < B; ++f) {                                                 // ordered replay of :591-823
+                if (!(nde < n_frame_errors && experiment <= n_experiments)) { stop = true; break; }
+                ++experiment; ++used;
+                const int iter = iters[(size_t)f];
+                sum_abs_iters += iter < 0 ? -iter : iter;
+                if (info[(size_t)f] != 0) {                                                      // bit 30: any wrong bit (:805)
+                    nse += info[(size_t)f] & ((1 << 30) - 1); ++nde;
+                    if (iter >= 0) ++nue;
+                    if (show_process)
+                        printf("SNR=%5.3lf,step=%4d,s_ers=%d,f_ers=%d,u_ers=%d,BER=%5.3le,FER=%5.3le\n", snr, (int)experiment,
+                               (int)nse, (int)nde, (int)nue, (double)nse / experiment / (n - r), (double)nde / experiment);
+                    if (nde >= 10 && (double)nde / experiment > 2.5 * reference_frame_error) { stop = true; break; }   // :820
+                }
+            }
+            if (used < B) {  // stopped inside the batch: put the generator where the frame-by-frame loop leaves it
+                if (ldpc_hip_mt_set_state_multi(ctx, mt_words, mt_pos) != 0) Env::fail(ldpc_hip_last_error());
+                if (ldpc_hip_mt_advance_multi(ctx, snr, modulation_type, punctured_blocks, used) != 0) Env::fail(ldpc_hip_last_error());
+            }
+            if (batch < cap) batch = batch * 4 < cap ? batch * 4 : cap;
+        }
+        if (ldpc_hip_mt_get_state_multi(ctx, mt_words, &mt_pos) != 0) Env::fail(ldpc_hip_last_error());
+        if (!mt_import(Env::generator(), mt_words, mt_pos)) Env::fail("bp_simulation: could not hand the generator state back to std::mt19937");
+        stop = true;   // the host-noise loop below is skipped
+    }
+    while (!device_noise && !stop && nde < n_frame_errors && experiment <= n_experiments) {     // :591
         const long long room = (long long)n_experiments + 1 - experiment;
         const long long B = batch < room ? batch : room;
         llr.resize((size_t)B * n); decword.resize((size_t)B * n); iters.resize((size_t)B);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDPC_HIP_ABI_VERSION 2
+#define LDPC_HIP_ABI_VERSION 3
 
 /* decoders.h:16-28 enum DEC_ID (only the binary decoders on the hot path are built) */
 #define LDPC_HIP_BP_DEC 0  /* bp_decod_qc_lm         decoders.cpp:1708 (Gallager BP, log domain) */
@@ -87,7 +87,7 @@ const char *ldpc_hip_last_launch(const ldpc_hip_ctx *ctx);
  * FMA-capable x86-64 host (fp64 in upstream's operation order, no FMA contraction; exp() is evaluated with that glibc's own
  * algorithm and evaluation order -- an upstream linked against another libm, e.g. MSVC's from the vs2005/vs2010 projects, may
  * differ from it, and so from this library, in the last ulp of soft values; hard decisions and return values are expected equal);
- * BP: hard decisions and return values identical, soft values within rtol 1e-5 / atol 1e-7 (its exp / log are the device's).
+ * BP: likewise bit for bit (its exp / log are glibc's algorithms on the device too).
  *   d_soft  [B][N] float64 out, or NULL: the a-posteriori values upstream writes to decword[] when decision==1
  *           (MS/LMS: LLR; SP: likelihood ratio = what upstream leaves in soft[])
  */
@@ -192,6 +192,35 @@ int ldpc_hip_simulate(ldpc_hip_ctx *ctx, double snr_db, int modulation_type, int
                       double alpha, uint64_t seed, long long first_frame, long long B,
                       unsigned long long counters[4], unsigned long long *sum_abs_iters);
 
+/* ---- upstream's own noise, bit for bit, on the device (exact replay at device speed) --------------------------------------
+ * bp_simulation() draws every noise sample from ONE std::mt19937 through next_random_gaussian(), a fresh
+ * std::normal_distribution<double> per call (commons_portable.cpp:140,174-178; bp_simulation.cpp:600-611).  These entry points
+ * continue THAT stream on the GPU: the context holds a generator state in std::mt19937's own terms -- the 624 state words and
+ * the index of the next word, exactly what `os << generator` prints with libstdc++ -- and every call below consumes from it
+ * precisely the 32-bit words the host loop would (four per polar-method attempt, libstdc++ bits/random.tcc:1802-1835,3348-3380).
+ * Values equal the host's bit for bit on a host whose libm log() is glibc >= 2.28's FMA variant (the contract of the decoders'
+ * exp / log above).  ldpc::bp_simulation_t (include/ldpc/bp_simulation.h) and the drop-in bp_simulation symbol use them, so the
+ * exact-replay harness is no longer bound by the host generator (~7e3 frames/s per core at N = 2048). */
+/* host only, no GPU: the state 2^log2_words words further on (20 <= log2_words <= 29), as the device computes it: GF(2)
+ * polynomial jump x^(2^k) mod the generator's minimal polynomial.  state_out[1..623] are the generator's words; of state_out[0]
+ * only bit 31 is state (the recurrence never reads the rest). */
+int ldpc_hip_mt_jump_host(const uint32_t state_in[624], int log2_words, uint32_t state_out[624]);
+/* Load / read the generator: state[624] + pos (0..624) as libstdc++ streams a std::mt19937.  set also restarts the context's frame
+ * count (which of the ldpc_hip_set_codewords codewords a frame carries: frame f -> codeword f % ncw). */
+int ldpc_hip_mt_set_state(ldpc_hip_ctx *ctx, const uint32_t state[624], int pos);
+int ldpc_hip_mt_get_state(ldpc_hip_ctx *ctx, uint32_t state[624], int *pos);
+/* The next `count` values of next_random_gaussian() (commons_portable.cpp:174-178) to d_out [count] (device; NULL = draw and drop). */
+int ldpc_hip_mt_normal_dev(ldpc_hip_ctx *ctx, long long count, double *d_out, void *stream);
+/* Decoder input of the next B frames exactly as the frame loop builds it: y = -2*(sigma*g + 2*c - 1)/sigma^2 with g drawn in index
+ * order (bp_simulation.cpp:600-611, sigma :445 / :449; c = 0 unless ldpc_hip_set_codewords), inverse interleaver (:684,
+ * ldpc_hip_set_interleaver), puncturing (:697-710).  modulation_type 0 or 1.  d_llr [B][N] device, NULL = draw and drop (used to put
+ * the generator where a frame-by-frame loop that stopped early would have left it).  Synchronises `stream`. */
+int ldpc_hip_mt_llr_dev(ldpc_hip_ctx *ctx, double snr_db, int modulation_type, int punctured_blocks, long long B, double *d_llr, void *stream);
+/* ldpc_hip_mt_llr_dev -> decode -> count for the next B frames; HOST arrays frame_info[B], iters[B] as in ldpc_hip_frames_multi.
+ * Synchronous.  The stopping rule (bp_simulation.cpp:591,820) is the caller's, on the ordered records. */
+int ldpc_hip_mt_frames(ldpc_hip_ctx *ctx, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha, long long B,
+                       int32_t *frame_info, int32_t *iters);
+
 /* ---- several GPUs of one node (bp_simulation's frame loop sharded; north_star: RCCL all-reduce for the counters only) ----
  * One shard = one context + one HIP stream + one host thread.  devices[i] is the HIP ordinal of shard i; ordinals may repeat
  * (logical shards on one GPU: results are identical, the counters are then summed on the host because RCCL does not accept one
@@ -219,6 +248,14 @@ int ldpc_hip_frames_multi(ldpc_hip_multi *m, double snr_db, int modulation_type,
  * on is sequential by definition and runs on shard 0). */
 int ldpc_hip_decode_host_multi(ldpc_hip_multi *m, double *llr, long long B, int maxiter, int decision, double alpha, double *decword,
                                int32_t *iters, int clobber_sp_input);
+/* The exact-replay stream (ldpc_hip_mt_*) over the shards: every shard runs the same generator over the whole batch -- the stream
+ * is sequential by nature and costs a fraction of the decode -- and decodes its contiguous slice of the B frames; the records come
+ * back in frame order.  advance = draw and drop B frames on every shard (roll-forward after an early stop). */
+int ldpc_hip_mt_set_state_multi(ldpc_hip_multi *m, const uint32_t state[624], int pos);
+int ldpc_hip_mt_get_state_multi(ldpc_hip_multi *m, uint32_t state[624], int *pos);
+int ldpc_hip_mt_advance_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, long long B);
+int ldpc_hip_mt_frames_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha,
+                             long long B, int32_t *frame_info, int32_t *iters);
 
 /* Timing aid for bench.py: average duration in milliseconds of the decode kernel launches recorded with
  * HIP events on their own stream since the last reset (events are only recorded while enabled). */

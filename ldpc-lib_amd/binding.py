@@ -115,7 +115,13 @@ def load_library():
     lib.ldpc_hip_simulate_multi.argtypes = [vp, f64, i32, i32, i32, f64, u64, i64, i64, i64, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.ldpc_hip_frames_multi.argtypes = [vp, f64, i32, i32, i32, f64, u64, i64, i64, i64, vp, vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.ldpc_hip_decode_host_multi.argtypes = [vp, vp, i64, i32, i32, f64, vp, vp, i32]
-    if lib.ldpc_hip_abi_version() != 2:
+    lib.ldpc_hip_mt_jump_host.argtypes = [vp, i32, vp]
+    lib.ldpc_hip_mt_set_state.argtypes = [vp, vp, i32]
+    lib.ldpc_hip_mt_get_state.argtypes = [vp, vp, C.POINTER(i32)]
+    lib.ldpc_hip_mt_normal_dev.argtypes = [vp, i64, vp, vp]
+    lib.ldpc_hip_mt_llr_dev.argtypes = [vp, f64, i32, i32, i64, vp, vp]
+    lib.ldpc_hip_mt_frames.argtypes = [vp, f64, i32, i32, i32, f64, i64, vp, vp]
+    if lib.ldpc_hip_abi_version() != 3:
         raise LdpcHipError("libldpc_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -248,6 +254,47 @@ class LdpcHip:
         _check(self.lib, rc, "ldpc_hip_simulate")
         return {"nse": cnt[0], "nde": cnt[1], "nue": cnt[2], "frames": cnt[3], "sum_abs_iters": sit.value}
 
+    # ---- upstream's own mt19937 / normal_distribution noise stream on the device (exact replay) ----------
+    def mt_set_state(self, state, pos):
+        """state: 624 uint32 words + index of the next word, as libstdc++ streams a std::mt19937."""
+        st = np.ascontiguousarray(state, dtype=np.uint32)
+        assert st.shape == (624,)
+        _check(self.lib, self.lib.ldpc_hip_mt_set_state(self.h, st.ctypes.data, int(pos)), "ldpc_hip_mt_set_state")
+
+    def mt_get_state(self):
+        st = np.empty(624, dtype=np.uint32)
+        pos = C.c_int()
+        _check(self.lib, self.lib.ldpc_hip_mt_get_state(self.h, st.ctypes.data, C.byref(pos)), "ldpc_hip_mt_get_state")
+        return st, pos.value
+
+    def mt_normal(self, count, out=None, skip=False, stream=None):
+        """The next `count` values of upstream's next_random_gaussian() (float64 CUDA tensor); skip=True draws and drops them."""
+        import torch
+        if not skip and out is None:
+            out = torch.empty(int(count), dtype=torch.float64, device=self._dev())
+        rc = self.lib.ldpc_hip_mt_normal_dev(self.h, int(count), None if skip else C.c_void_p(out.data_ptr()), _stream_ptr(stream))
+        _check(self.lib, rc, "ldpc_hip_mt_normal_dev")
+        return out
+
+    def mt_llr(self, snr_db, B, modulation=0, punctured_blocks=0, out=None, skip=False, stream=None):
+        """Decoder input of the next B frames of upstream's frame loop ([B,N] float64 CUDA tensor); skip=True only advances."""
+        import torch
+        if not skip and out is None:
+            out = torch.empty((int(B), self.N), dtype=torch.float64, device=self._dev())
+        rc = self.lib.ldpc_hip_mt_llr_dev(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(B),
+                                          None if skip else C.c_void_p(out.data_ptr()), _stream_ptr(stream))
+        _check(self.lib, rc, "ldpc_hip_mt_llr_dev")
+        return out
+
+    def mt_frames(self, snr_db, maxiter, B, modulation=0, punctured_blocks=0, alpha=0.8):
+        """noise -> decode -> count for the next B frames: (frame_info[B], iters[B]) int32 numpy arrays."""
+        info = np.empty(int(B), dtype=np.int32)
+        its = np.empty(int(B), dtype=np.int32)
+        rc = self.lib.ldpc_hip_mt_frames(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(maxiter), float(alpha), int(B),
+                                         info.ctypes.data, its.ctypes.data)
+        _check(self.lib, rc, "ldpc_hip_mt_frames")
+        return info, its
+
     # ---- host-pointer API (upstream array layout, PCIe inclusive) --------------------------------------
     def decode_host(self, llr, maxiter, decision=0, alpha=0.8, clobber_sp_input=True):
         """llr: float64 [B,N] or [N].  Returns (decword, iters, llr_after) like the upstream decoder call: decword is
@@ -352,6 +399,15 @@ class LdpcHipMulti:
                                                  its.ctypes.data, 1 if clobber_sp_input else 0)
         _check(self.lib, rc, "ldpc_hip_decode_host_multi")
         return dec, its, llr
+
+
+def mt_jump_host(state, log2_words):
+    """mt19937 state 2**log2_words words further on (host, no GPU): the library's GF(2) polynomial jump."""
+    lib = load_library()
+    st = np.ascontiguousarray(state, dtype=np.uint32)
+    out = np.empty(624, dtype=np.uint32)
+    _check(lib, lib.ldpc_hip_mt_jump_host(st.ctypes.data, int(log2_words), out.ctypes.data), "ldpc_hip_mt_jump_host")
+    return out
 
 
 def qam_modulate(bits, Q, device=0, stream=None):

@@ -25,6 +25,7 @@
 #include "ldpc_spec.hpp"
 #include "code_appendix_c_m64.hpp"
 #include "ldpc_sumprod.hpp"
+#include "ldpc_mt.hpp"
 
 namespace {
 
@@ -231,6 +232,8 @@ struct ldpc_hip_ctx {
     uint8_t *d_tx = nullptr;              // [ncw][ntx] bits in channel order, zero padded to whole symbols
     uint32_t *d_cw_packed = nullptr;      // [ncw][hard_words]
     int32_t *d_scatter = nullptr;         // [N] decoder index of channel bit j
+    // exact replay of upstream's noise on the device (ldpc_mt.hpp, ldpc_hip_mt_*)
+    ldpc_mt::DeviceState mt;
     // HIP-event timing of decode launches
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -538,6 +541,7 @@ void ldpc_hip_close(ldpc_hip_ctx *c) {
     if (c->d_tx) (void)hipFree(c->d_tx);
     if (c->d_cw_packed) (void)hipFree(c->d_cw_packed);
     if (c->d_scatter) (void)hipFree(c->d_scatter);
+    ldpc_mt::release(c->mt);
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete c;
 }
@@ -787,7 +791,6 @@ static int prepare_chain(ldpc_hip_ctx *c, int modulation_type) {
     const int N = c->N, halfmlog = modulation_type <= 1 ? 1 : modulation_type;   // bp_simulation.cpp:402-411
     const int m = modulation_type <= 1 ? 2 : 2 * modulation_type;
     const int ntx = modulation_type <= 1 ? N : ((N + m - 1) / m) * m;           // extra_bits of :575, zero
-    if (c->d_glob_ws) (void)hipFree(c->d_glob_ws);
     if (c->d_tx) (void)hipFree(c->d_tx);
     if (c->d_cw_packed) (void)hipFree(c->d_cw_packed);
     if (c->d_scatter) (void)hipFree(c->d_scatter);
@@ -1071,4 +1074,5 @@ int ldpc_hip_profile_read(ldpc_hip_ctx *c, double *total_ms, long long *launches
 
 }  // extern "C"
 
+#include "ldpc_mt_api.hpp"
 #include "ldpc_multi.hpp"

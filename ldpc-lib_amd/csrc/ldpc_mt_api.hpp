@@ -1,0 +1,217 @@
+// ldpc_mt_api.hpp -- host side of the exact-replay noise generator (kernels: ldpc_mt.hpp); included at the end of ldpc_hip.hip.
+#pragma once
+
+namespace {
+
+int mt_prepare(ldpc_hip_ctx *c) {
+    ldpc_mt::DeviceState &m = c->mt;
+    if (m.d_poly) return 0;
+    const ldpc_mt::JumpPolys &J = ldpc_mt::jump_polys();
+    if (!J.ok) return fail(LDPC_HIP_EUNSUPPORTED, "mt19937 jump polynomials: %s", J.err.c_str());
+    HIP_TRY(hipMalloc(&m.d_state, sizeof(uint32_t) * ldpc_mt::MTN));
+    HIP_TRY(hipMalloc(&m.d_total, sizeof(unsigned long long) * 2));
+    HIP_TRY(hipMalloc(&m.d_end_t, sizeof(long long) * 2));
+    HIP_TRY(hipMalloc(&m.d_poly, sizeof(uint32_t) * J.poly.size()));
+    HIP_TRY(hipMemcpy(m.d_poly, J.poly.data(), sizeof(uint32_t) * J.poly.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_mt::mt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(uint32_t) * ldpc_mt::kSeqWords)));
+    return 0;
+}
+
+// One generation round on `st`: draws from the context's generator until `need` items exist or the round's words run out, emits
+// min(need, produced) items (whole frames when proto.per_frame != 0) through proto.out, and moves the generator to the word after
+// the last emitted item.  Synchronises the stream (the count of accepted attempts decides how far the round got).
+int mt_round(ldpc_hip_ctx *c, unsigned long long need, ldpc_mt::PolarArgs proto, unsigned long long *emitted, hipStream_t st) {
+    using namespace ldpc_mt;
+    DeviceState &m = c->mt;
+    const double g = (double)need;
+    // attempts for `need` accepted ones at p = pi/4, plus ~8 standard deviations (negative binomial: sd = 0.59 sqrt(need))
+    const long long A = (long long)(g * 1.2732395447351628 + 5.0 * std::sqrt(g) + 64.0);
+    long long S = (m.pos + 4 * A + kStride - 1) / kStride;
+    if (S < 1) S = 1;
+    if (S > kMaxStreams) S = kMaxStreams;
+    const size_t words = (size_t)MTN + (size_t)S * (size_t)kStride;
+    if (S > m.cap_streams) {
+        if (m.d_states) (void)hipFree(m.d_states);
+        m.d_states = nullptr; m.cap_streams = 0;
+        HIP_TRY(hipMalloc(&m.d_states, sizeof(uint32_t) * MTN * (size_t)S));
+        m.cap_streams = (int)S;
+    }
+    if (words > m.cap_words) {
+        if (m.d_xraw) (void)hipFree(m.d_xraw);
+        m.d_xraw = nullptr; m.cap_words = 0;
+        HIP_TRY(hipMalloc(&m.d_xraw, sizeof(uint32_t) * words));
+        m.cap_words = words;
+    }
+    const long long attempts = ((long long)S * kStride - m.pos) / 4;   // the last 624 words stay unread: they are the next state
+    const long long nb = (attempts + 256 * kPolarSub - 1) / (256 * kPolarSub);
+    if (nb > m.cap_blocks) {
+        if (m.d_blockcnt) (void)hipFree(m.d_blockcnt);
+        if (m.d_blockbase) (void)hipFree(m.d_blockbase);
+        m.d_blockcnt = nullptr; m.d_blockbase = nullptr; m.cap_blocks = 0;
+        HIP_TRY(hipMalloc(&m.d_blockcnt, sizeof(uint32_t) * (size_t)nb));
+        HIP_TRY(hipMalloc(&m.d_blockbase, sizeof(unsigned long long) * (size_t)nb));
+        m.cap_blocks = nb;
+    }
+    HIP_TRY(hipMemcpyAsync(m.d_states, m.d_state, sizeof(uint32_t) * MTN, hipMemcpyDeviceToDevice, st));
+    for (int level = 0; (1ll << level) < S; ++level) {   // stream j + 2^level from stream j, j < 2^level
+        const long long have = 1ll << level, cnt = have < S - have ? have : S - have;
+        JumpArgs ja{m.d_states, m.d_poly + (size_t)level * MTN, 0, (int)have};
+        hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)cnt), dim3(640), sizeof(uint32_t) * kSeqWords, st, ja);
+    }
+    GenArgs ga{m.d_states, m.d_xraw, (int)S};
+    hipLaunchKernelGGL(mt_generate_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, ga);
+    proto.xraw = m.d_xraw; proto.p = m.pos; proto.attempts = attempts;
+    proto.blockcnt = m.d_blockcnt; proto.blockbase = m.d_blockbase; proto.total = m.d_total; proto.need = need; proto.end_t = m.d_end_t;
+    hipLaunchKernelGGL(mt_polar_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, proto);
+    hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(1024), 0, st, m.d_blockcnt, m.d_blockbase, m.d_total, nb);
+    m.h_end = m.pos;
+    HIP_TRY(hipMemcpyAsync(m.d_end_t, &m.h_end, sizeof(long long), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mt_polar_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, proto);
+    hipLaunchKernelGGL(mt_adopt_kernel, dim3(1), dim3(640), 0, st, m.d_xraw, m.d_end_t, m.d_state);
+    HIP_TRY(hipGetLastError());
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, m.d_total, sizeof total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    m.pos = 0;
+    unsigned long long lim = total < need ? total : need;
+    if (proto.per_frame) lim -= lim % (unsigned long long)proto.per_frame;
+    *emitted = lim;
+    return 0;
+}
+
+// LLR rows of the next B frames of the generator's stream; of those, frames [lo, hi) are written to d_rows ([hi - lo][N]); d_rows
+// may be null (the frames are drawn and dropped).
+int mt_llr_rows(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, long long B, long long lo, long long hi,
+                double *d_rows, hipStream_t st) {
+    using namespace ldpc_mt;
+    DeviceState &m = c->mt;
+    if (!m.set) return fail(LDPC_HIP_EINVAL, "the generator has no state: call ldpc_hip_mt_set_state first");
+    if (modulation_type != 0 && modulation_type != 1)
+        return fail(LDPC_HIP_EUNSUPPORTED, "exact replay covers modulation_type 0 (BPSK) and 1 (QAM4): upstream's QAM16+ wiring is broken (SURVEY Appendix B Q5/Q6)");
+    if ((unsigned long long)c->N > kRoundItems) return fail(LDPC_HIP_EUNSUPPORTED, "code length %d is beyond one generation round", c->N);
+    PolarArgs a{};
+    if (int rc = awgn_sigma(c, snr_db, modulation_type, punctured_blocks, &a.sigma)) return rc;
+    if (int rc = prepare_chain(c, modulation_type)) return rc;
+    a.per_frame = c->N;
+    a.tx = c->ncw > 0 ? c->d_tx : nullptr; a.ncw = c->ncw > 0 ? c->ncw : 1; a.ntx = c->chain_ntx;
+    a.scatter = c->d_scatter;
+    a.punct_start = c->N - c->M * punctured_blocks;
+    a.punct_val = (c->decoder_id == LDPC_HIP_SP_DEC || c->decoder_id == LDPC_HIP_TASP_DEC || c->decoder_id == LDPC_HIP_ASP_DEC) ? 0.0 : 0.5;  // :700 (sic)
+    const long long per_round = (long long)(kRoundItems / (unsigned long long)c->N) > 0 ? (long long)(kRoundItems / (unsigned long long)c->N) : 1;
+    long long done = 0;
+    while (done < B) {
+        const long long fr = B - done < per_round ? B - done : per_round;
+        const long long r_lo = lo > done ? lo : done, r_hi = hi < done + fr ? hi : done + fr;
+        a.first_frame = m.frames_taken;
+        if (d_rows && r_lo < r_hi) { a.row_lo = r_lo - done; a.row_hi = r_hi - done; a.out = d_rows + (r_lo - lo) * (long long)c->N; }
+        else { a.row_lo = 0; a.row_hi = 0; a.out = nullptr; }
+        unsigned long long emitted = 0;
+        if (int rc = mt_round(c, (unsigned long long)fr * (unsigned long long)c->N, a, &emitted, st)) return rc;
+        const long long fdone = (long long)(emitted / (unsigned long long)c->N);
+        done += fdone;
+        m.frames_taken += fdone;
+    }
+    return 0;
+}
+
+// frames [lo, hi) of the next B frames: noise -> decode -> count on `st`; records to HOST arrays info[hi - lo], iters[hi - lo]
+int mt_frames_slice(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha, long long B,
+                    long long lo, long long hi, int32_t *info, int32_t *iters, hipStream_t st) {
+    ldpc_mt::DeviceState &m = c->mt;
+    const long long mine = hi - lo;
+    if (mine > m.cap_rec) {
+        if (m.d_info) (void)hipFree(m.d_info);
+        if (m.d_iters) (void)hipFree(m.d_iters);
+        m.d_info = nullptr; m.d_iters = nullptr; m.cap_rec = 0;
+        HIP_TRY(hipMalloc(&m.d_info, sizeof(int32_t) * (size_t)mine));
+        HIP_TRY(hipMalloc(&m.d_iters, sizeof(int32_t) * (size_t)mine));
+        m.cap_rec = mine;
+    }
+    long long chunk_max = ((long long)8 << 30) / ((long long)sizeof(double) * c->N);
+    chunk_max = chunk_max > (1 << 16) ? (1 << 16) : (chunk_max < 1 ? 1 : chunk_max);
+    const long long first = m.frames_taken;
+    for (long long c0 = 0; c0 < B; c0 += chunk_max) {
+        const long long c1 = c0 + chunk_max < B ? c0 + chunk_max : B;
+        const long long r_lo = lo > c0 ? lo : c0, r_hi = hi < c1 ? hi : c1, rows = r_hi > r_lo ? r_hi - r_lo : 0;
+        if (rows > 0) { if (int rc = ensure_workspace(c, rows, false)) return rc; }
+        if (int rc = mt_llr_rows(c, snr_db, modulation_type, punctured_blocks, c1 - c0, rows > 0 ? r_lo - c0 : 0, rows > 0 ? r_hi - c0 : 0,
+                                 rows > 0 ? c->w_llr : nullptr, st))
+            return rc;
+        if (rows == 0) continue;
+        int32_t *it = m.d_iters + (r_lo - lo);
+        if (int rc = ldpc_hip_decode_dev(c, c->w_llr, rows, maxiter, alpha, c->w_hard, it, nullptr, st)) return rc;
+        if (int rc = ldpc_hip_count_errors_cw_dev(c, c->w_hard, it, first + r_lo, rows, m.d_info + (r_lo - lo), c->w_counters, st)) return rc;
+    }
+    if (mine > 0) {
+        HIP_TRY(hipMemcpyAsync(info, m.d_info, sizeof(int32_t) * (size_t)mine, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(iters, m.d_iters, sizeof(int32_t) * (size_t)mine, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ldpc_hip_mt_jump_host(const uint32_t state_in[624], int log2_words, uint32_t state_out[624]) {
+    if (!state_in || !state_out || log2_words < ldpc_mt::kLog2Stride || log2_words >= ldpc_mt::kLog2Stride + ldpc_mt::kLevels)
+        return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_jump_host: log2_words must be in [%d, %d]", ldpc_mt::kLog2Stride, ldpc_mt::kLog2Stride + ldpc_mt::kLevels - 1);
+    const ldpc_mt::JumpPolys &J = ldpc_mt::jump_polys();
+    if (!J.ok) return fail(LDPC_HIP_EUNSUPPORTED, "mt19937 jump polynomials: %s", J.err.c_str());
+    ldpc_mt::jump_host(state_in, J.poly.data() + (size_t)(log2_words - ldpc_mt::kLog2Stride) * ldpc_mt::MTN, state_out);
+    return 0;
+}
+
+int ldpc_hip_mt_set_state(ldpc_hip_ctx *c, const uint32_t state[624], int pos) {
+    if (!c || !state || pos < 0 || pos > 624) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_set_state: bad argument");
+    if (int rc = set_device(c)) return rc;
+    if (int rc = mt_prepare(c)) return rc;
+    HIP_TRY(hipMemcpy(c->mt.d_state, state, sizeof(uint32_t) * ldpc_mt::MTN, hipMemcpyHostToDevice));
+    c->mt.pos = pos;
+    c->mt.set = true;
+    c->mt.frames_taken = 0;
+    return 0;
+}
+
+int ldpc_hip_mt_get_state(ldpc_hip_ctx *c, uint32_t state[624], int *pos) {
+    if (!c || !state || !pos) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_get_state: bad argument");
+    if (!c->mt.set) return fail(LDPC_HIP_EINVAL, "the generator has no state: call ldpc_hip_mt_set_state first");
+    if (int rc = set_device(c)) return rc;
+    HIP_TRY(hipMemcpy(state, c->mt.d_state, sizeof(uint32_t) * ldpc_mt::MTN, hipMemcpyDeviceToHost));
+    *pos = c->mt.pos;
+    return 0;
+}
+
+int ldpc_hip_mt_normal_dev(ldpc_hip_ctx *c, long long count, double *d_out, void *stream_) {
+    if (!c || count < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_normal_dev: bad argument");
+    if (!c->mt.set) return fail(LDPC_HIP_EINVAL, "the generator has no state: call ldpc_hip_mt_set_state first");
+    if (int rc = set_device(c)) return rc;
+    hipStream_t st = (hipStream_t)stream_;
+    long long done = 0;
+    while (done < count) {
+        const unsigned long long want = (unsigned long long)(count - done) < ldpc_mt::kRoundItems ? (unsigned long long)(count - done) : ldpc_mt::kRoundItems;
+        ldpc_mt::PolarArgs a{};
+        a.out = d_out ? d_out + done : nullptr;
+        unsigned long long emitted = 0;
+        if (int rc = mt_round(c, want, a, &emitted, st)) return rc;
+        done += (long long)emitted;
+    }
+    return 0;
+}
+
+int ldpc_hip_mt_llr_dev(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, long long B, double *d_llr, void *stream_) {
+    if (!c || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_llr_dev: bad argument");
+    if (int rc = set_device(c)) return rc;
+    return mt_llr_rows(c, snr_db, modulation_type, punctured_blocks, B, 0, B, d_llr, (hipStream_t)stream_);
+}
+
+int ldpc_hip_mt_frames(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha, long long B,
+                       int32_t *frame_info, int32_t *iters) {
+    if (!c || B < 0 || !frame_info || !iters) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_frames: bad argument");
+    if (int rc = set_device(c)) return rc;
+    return mt_frames_slice(c, snr_db, modulation_type, punctured_blocks, maxiter, alpha, B, 0, B, frame_info, iters, nullptr);
+}
+
+}  // extern "C"

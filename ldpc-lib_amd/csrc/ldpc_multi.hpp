@@ -260,4 +260,41 @@ int ldpc_hip_decode_host_multi(ldpc_hip_multi *m, double *llr, long long B, int 
     });
 }
 
+// ---- exact replay over the shards: every shard runs the SAME generator over the whole batch (the stream is sequential by nature
+// and generating it costs a fraction of the decode) and decodes its contiguous slice of the frames; no exchange at all.
+int ldpc_hip_mt_set_state_multi(ldpc_hip_multi *m, const uint32_t state[624], int pos) {
+    if (!m) return fail(LDPC_HIP_EINVAL, "null multi context");
+    for (ldpc_hip_ctx *c : m->shard) if (int rc = ldpc_hip_mt_set_state(c, state, pos)) return rc;
+    return 0;
+}
+
+int ldpc_hip_mt_get_state_multi(ldpc_hip_multi *m, uint32_t state[624], int *pos) {
+    if (!m) return fail(LDPC_HIP_EINVAL, "null multi context");
+    return ldpc_hip_mt_get_state(m->shard[0], state, pos);
+}
+
+int ldpc_hip_mt_advance_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, long long B) {
+    if (!m || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_advance_multi: bad argument");
+    return for_each_shard(m, [&](int i) -> int {
+        ldpc_hip_ctx *c = m->shard[(size_t)i];
+        if (int r = set_device(c)) return r;
+        return mt_llr_rows(c, snr_db, modulation_type, punctured_blocks, B, 0, 0, nullptr, m->stream[(size_t)i]);
+    });
+}
+
+int ldpc_hip_mt_frames_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha,
+                             long long B, int32_t *frame_info, int32_t *iters) {
+    if (!m || B < 0 || !frame_info || !iters) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_frames_multi: bad argument");
+    const int n = (int)m->shard.size();
+    // BP_DEC with the frame chain on is sequential by definition (decoders.cpp:1742-1762): shard 0 decodes the whole batch
+    const bool chained = m->shard[0]->decoder_id == LDPC_HIP_BP_DEC && m->shard[0]->bp_chain;
+    return for_each_shard(m, [&](int i) -> int {
+        ldpc_hip_ctx *c = m->shard[(size_t)i];
+        if (int r = set_device(c)) return r;
+        long long lo = B * i / n, hi = B * (i + 1) / n;
+        if (chained) { lo = i == 0 ? 0 : B; hi = B; }
+        return mt_frames_slice(c, snr_db, modulation_type, punctured_blocks, maxiter, alpha, B, lo, hi, frame_info + lo, iters + lo, m->stream[(size_t)i]);
+    });
+}
+
 }  // extern "C"

@@ -1,0 +1,218 @@
+"""Upstream's noise stream on the device (ldpc_hip_mt_*, csrc/ldpc_mt.hpp): std::mt19937 + a fresh std::normal_distribution<double>
+per sample (commons_portable.cpp:140,174-178), continued on the GPU bit for bit.
+
+CPU part: the GF(2) jump polynomials against a plain walk of the recurrence (numpy's MT19937 bit generator is the same public
+algorithm).  GPU part: samples, LLR rows and generator state against the oracle's std:: objects (oracle/harness_oracle.cpp), and the
+C++ harness with the noise on the device against the sequential restatement of upstream's frame loop."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from ldpc_testlib import MS_DEC, LMS_DEC, SP_DEC, TASP_DEC, BP_DEC, load_base_matrix, oracle_lib, relift, awgn_llr, code_rate
+
+
+def seeded_state(seed):
+    """std::mt19937(seed): init_genrand's 624 words, position 624 (the first draw regenerates the block)."""
+    bg = np.random.MT19937()
+    bg._legacy_seeding(int(seed))
+    st = bg.state["state"]
+    return st["key"].astype(np.uint32).copy(), int(st["pos"])
+
+
+def raw_after(key, pos, skip, n):
+    """tempered outputs skip .. skip+n of the generator (key, pos)"""
+    bg = np.random.MT19937()
+    s = bg.state
+    s["state"]["key"] = np.array(key, dtype=np.uint32)
+    s["state"]["pos"] = int(pos)
+    bg.state = s
+    if skip:
+        bg.random_raw(int(skip))
+    return bg.random_raw(int(n)).astype(np.uint32)
+
+
+def oracle_gaussians(seed, n, burn=0):
+    out = np.empty(n, dtype=np.float64)
+    oracle_lib().orc_rng_gaussians(int(seed), int(burn), out.ctypes.data_as(C.POINTER(C.c_double)), int(n))
+    return out
+
+
+@pytest.fixture(scope="module")
+def L():
+    import ldpc_lib_amd
+    ldpc_lib_amd.build_library()
+    return ldpc_lib_amd
+
+
+@pytest.mark.parametrize("log2_words", [20, 21, 24, 26])
+def test_jump_polynomial_equals_a_plain_walk(L, log2_words):
+    """state after 2^k words by x^(2^k) mod phi == the recurrence walked 2^k words (numpy's MT19937)."""
+    from ldpc_lib_amd.binding import mt_jump_host
+    key, _ = seeded_state(20240607 + log2_words)
+    jumped = mt_jump_host(key, log2_words)
+    J = 1 << log2_words
+    # sequence origin: x[0..624) = key; outputs from position 624 on are temper(x[624 + i])
+    want = raw_after(key, 624, J, 1500)            # temper(x[J + 624 + i])
+    got = raw_after(jumped, 624, 0, 1500)          # the same words from the jumped state (word 0: only bit 31 is state)
+    assert np.array_equal(want, got)
+    # words 1..623 of the jumped state are x[J + 1 ..]: temper them and compare with the walk's outputs J - 623 .. J
+    direct = raw_after(key, 624, J - 623, 623)     # temper(x[J + 1 .. J + 623])
+    assert np.array_equal(direct, raw_after(jumped, 1, 0, 623))
+
+
+def test_jump_levels_compose(L):
+    """jump(2^29) == jump(2^28) twice (the longest stride is too long to walk in a test)."""
+    from ldpc_lib_amd.binding import mt_jump_host
+    key, _ = seeded_state(77)
+    once = mt_jump_host(key, 29)
+    twice = mt_jump_host(mt_jump_host(key, 28), 28)
+    assert np.array_equal(once[1:], twice[1:]) and (once[0] ^ twice[0]) & 0x80000000 == 0
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    if not t.cuda.is_available():
+        pytest.skip("no GPU")
+    return t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,burn,counts", [
+    (1, 0, [1, 7, 4096, 200000]),          # single stream, uneven pieces: every call continues where the last one stopped
+    (5, 1024, [3_000_000]),                # 15 streams: jump levels 0..3; the generator starts inside its block (position 400)
+    (9, 0, [30_000_000, 1000]),            # 146 streams, levels 0..7, then a short continuation
+])
+def test_device_samples_equal_the_hosts(L, torch, seed, burn, counts):
+    """next_random_gaussian() on the device == std::normal_distribution on the host, bit for bit, whatever the call split."""
+    H = relift(load_base_matrix(), 64)
+    total = sum(counts)
+    want = oracle_gaussians(seed, total, burn)
+    key, pos = seeded_state(seed)
+    if burn:   # next_random_int(0, 2) takes one word per draw: start inside the first regenerated block
+        bg = np.random.MT19937()
+        s = bg.state
+        s["state"]["key"] = key; s["state"]["pos"] = pos
+        bg.state = s
+        bg.random_raw(burn)
+        key, pos = bg.state["state"]["key"].astype(np.uint32), int(bg.state["state"]["pos"])
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        dec.mt_set_state(key, pos)
+        got = torch.cat([dec.mt_normal(c) for c in counts]).cpu().numpy()
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+        # the state handed back continues the host stream: its next words are what the host generator would draw next
+        st, p = dec.mt_get_state()
+        nxt = raw_after(st, p, 0, 2000)
+        # host: replay the same number of samples with the oracle and look at the values after them
+        more = oracle_gaussians(seed, total + 50, burn)[total:]
+        dec.mt_set_state(st, p)
+        assert np.array_equal(dec.mt_normal(50).cpu().numpy().view(np.uint64), more.view(np.uint64))
+        assert nxt.shape == (2000,)
+
+
+@pytest.mark.gpu
+def test_skipping_equals_drawing(L, torch):
+    H = relift(load_base_matrix(), 64)
+    key, pos = seeded_state(3)
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        dec.mt_set_state(key, pos)
+        dec.mt_normal(123457, skip=True)
+        a = dec.mt_normal(1000).cpu().numpy()
+        want = oracle_gaussians(3, 123457 + 1000)[123457:]
+        assert np.array_equal(a.view(np.uint64), want.view(np.uint64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,snr,frames,seed", [(64, 2.0, 300, 1), (1, 4.0, 5000, 2), (126, 1.7, 40, 3)])
+def test_device_llr_rows_equal_the_frame_loops(L, torch, M, snr, frames, seed):
+    """bp_simulation.cpp:512,600-605: codeword draws first, then N samples per frame -> y = -2 (sigma g - 1) / sigma^2."""
+    H = relift(load_base_matrix(), M)
+    want = awgn_llr(H, M, snr, seed, frames)
+    key, pos = seeded_state(seed)
+    bg = np.random.MT19937()
+    s = bg.state
+    s["state"]["key"] = key; s["state"]["pos"] = pos
+    bg.state = s
+    bg.random_raw((H.shape[1] - H.shape[0]) * M)       # random_codeword()'s next_random_int(0, 2) draws, one word each
+    key, pos = bg.state["state"]["key"].astype(np.uint32), int(bg.state["state"]["pos"])
+    with L.LdpcHip(MS_DEC, H, M) as dec:
+        dec.mt_set_state(key, pos)
+        first = dec.mt_llr(snr, frames // 3).cpu().numpy()
+        rest = dec.mt_llr(snr, frames - frames // 3).cpu().numpy()
+        got = np.concatenate([first, rest])
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def _compat(L):
+    import subprocess
+    L.load_library()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "ldpc-lib_amd", "csrc", "compat")])
+    lib = C.CDLL(os.path.join(root, "ldpc-lib_amd", "libldpc_compat.so"))
+    lib.ldpc_bp_simulation_exact_perm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p, C.c_void_p]
+    return lib
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("noise", ["device", "host"])
+@pytest.mark.parametrize("dec_id,M,snr,maxit,n_fe,n_exp,ref,mod,punct,seed,devices", [
+    (MS_DEC, 64, 2.0, 50, 10**9, 4000, 1.0, 0, 0, 1, "0"),          # cfg2: 170 / 4001
+    (MS_DEC, 64, 1.2, 50, 10**9, 5000, 0.02, 0, 0, 1, "0"),         # early stop on the FER rule: roll-back inside a batch
+    (MS_DEC, 64, 1.4, 50, 7, 5000, 1.0, 0, 0, 3, "0,0,0"),          # stops on n_frame_errors; three logical shards
+    (LMS_DEC, 64, 1.6, 50, 10**9, 300, 1.0, 1, 2, 9, "0,0"),        # QAM4 + two punctured blocks, two shards
+    (TASP_DEC, 126, 1.7, 15, 50, 10**8, 1.0, 0, 0, 1, "0"),         # the shipped scenario: 50 / 821
+    (BP_DEC, 64, 1.3, 30, 10**9, 250, 1.0, 0, 0, 2, "0,0"),         # frame chain: shard 0 decodes, both generators advance
+    (SP_DEC, 64, 1.9, 50, 10**9, 40000, 1.0, 0, 0, 4, "0"),         # a run long enough for the 32768-frame batches
+])
+def test_harness_with_the_noise_on_the_device(L, torch, monkeypatch, noise, dec_id, M, snr, maxit, n_fe, n_exp, ref, mod, punct, seed, devices):
+    """ldpc::bp_simulation_t with LDPC_HIP_EXACT_NOISE=device (default) / host == the sequential CPU restatement: counters, BER / FER
+    doubles and the next word of the generator afterwards."""
+    from ldpc_testlib import SimResult, c_int_p
+    if noise == "host" and n_exp > 6000:
+        pytest.skip("the host-noise harness is the slow one; the long run is for the device path")
+    monkeypatch.setenv("LDPC_HIP_EXACT_NOISE", noise)
+    monkeypatch.setenv("LDPC_HIP_DEVICES", devices)
+    lib = _compat(L)
+    H = np.ascontiguousarray(relift(load_base_matrix(), M), dtype=np.int32)
+    out = (C.c_double * 7)()
+    nxt = C.c_uint()
+    rc = lib.ldpc_bp_simulation_exact_perm(16, 32, H.ctypes.data, M, maxit, n_fe, n_exp, snr, ref, dec_id, mod, 0, 128, 1, punct, seed, 0,
+                                           C.addressof(out), C.addressof(nxt))
+    assert rc == 0
+    res = SimResult()
+    assert oracle_lib().orc_bp_simulation(16, 32, H.ctypes.data_as(c_int_p), M, maxit, n_fe, n_exp, snr, ref, dec_id, mod, punct,
+                                          seed, C.byref(res), None) == 0
+    assert (out[2], out[3], out[4], out[5], out[6]) == (res.nse, res.nde, res.nue, res.experiment, res.sum_abs_iter)
+    assert out[0] == res.ber and out[1] == res.fer
+    assert nxt.value == res.rng_next
+    if (dec_id, n_exp, seed) == (MS_DEC, 4000, 1):
+        assert (res.nde, res.experiment) == (170, 4001)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("perm_type,block,inter", [(3, 64, 1), (1, 128, 1)])
+def test_harness_on_the_device_with_an_interleaver(L, torch, monkeypatch, perm_type, block, inter):
+    from ldpc_testlib import SimResult, c_int_p
+    from ldpc_lib_amd.binding import build_interleaver
+    monkeypatch.setenv("LDPC_HIP_EXACT_NOISE", "device")
+    lib = _compat(L)
+    M = 64
+    H = np.ascontiguousarray(relift(load_base_matrix(), M), dtype=np.int32)
+    out = (C.c_double * 7)()
+    nxt = C.c_uint()
+    assert lib.ldpc_bp_simulation_exact_perm(16, 32, H.ctypes.data, M, 50, 10**9, 400, 1.8, 1.0, MS_DEC, 0, perm_type, block, inter, 0, 11, 0,
+                                             C.addressof(out), C.addressof(nxt)) == 0
+    _, inv = build_interleaver(H, M, perm_type, 1, block, inter)
+    inv = np.ascontiguousarray(inv, dtype=np.int32)
+    olib = oracle_lib()
+    olib.orc_bp_simulation_perm.argtypes = [C.c_int, C.c_int, c_int_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                            C.c_int, C.c_uint, c_int_p, C.POINTER(SimResult), c_int_p]
+    res = SimResult()
+    assert olib.orc_bp_simulation_perm(16, 32, H.ctypes.data_as(c_int_p), M, 50, 10**9, 400, 1.8, 1.0, MS_DEC, 0, 0, 11,
+                                       inv.ctypes.data_as(c_int_p), C.byref(res), None) == 0
+    assert (out[2], out[3], out[4], out[5]) == (res.nse, res.nde, res.nue, res.experiment)
+    assert out[0] == res.ber and out[1] == res.fer and nxt.value == res.rng_next
