@@ -196,7 +196,7 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
     if (device_noise) {
         if (ldpc_hip_multi_set_interleaver(ctx, permutation_type, permutation_block, permutation_inter) != 0) Env::fail(ldpc_hip_last_error());
         if (ldpc_hip_mt_set_state_multi(ctx, mt_words, mt_pos) != 0) Env::fail(ldpc_hip_last_error());
-        const long long cap = (max_batch > 32768 * (long long)devices.size()) ? max_batch : 32768 * (long long)devices.size();
+        const long long cap = (max_batch > 65536 * (long long)devices.size()) ? max_batch : 65536 * (long long)devices.size();
         std::vector<int32_t> info;
         batch = 256;
         while (!stop && nde < n_frame_errors && experiment <= n_experiments) {                  // :591

@@ -9,10 +9,11 @@
 //       ahead is g_J(F) applied to the state, g_J = x^J mod phi, phi = the minimal polynomial of the recurrence (degree 19937)
 //       [Haramoto, Matsumoto, Nishimura, Panneton, L'Ecuyer 2008].  With x^J = g_J mod phi every word of the sequence obeys
 //       x[t+J] = XOR over the set bits i of g_J of x[t+i] -- a GF(2) convolution over 19937 + 624 consecutive words
-//       (mt_jump_kernel, one workgroup per jump, the words in LDS).  The host computes phi (Berlekamp-Massey on an output bit
+//       (mt_jump_kernel: the words in LDS, up to 8 workgroups per jump, each taking a share of g_J's ~10^4 set coefficients).  The host computes phi (Berlekamp-Massey on an output bit
 //       sequence) and g_J for J = 2^20 .. 2^29 by repeated squaring once per process (~60 ms) and checks the first against a plain
 //       2^20-step walk.  S stream states are reached in ceil(log2 S) doubling rounds; then one WAVEFRONT per stream runs the
-//       recurrence through a 1024-word LDS ring, 192 words per step (mt_generate_kernel), writing the untempered words to HBM.
+//       recurrence in place over its 624-word block in LDS, 192 words per step with every LDS address an immediate offset
+//       (mt_generate_kernel), writing the untempered words to HBM.
 //   libstdc++'s normal_distribution (bits/random.tcc: Marsaglia polar method): an attempt takes four 32-bit words (two
 //       generate_canonical<double,53> values), is accepted with probability pi/4 and, because upstream constructs a new distribution
 //       per call, yields ONE value (the cached second one is dropped).  So sample k of the run is the k-th
@@ -39,6 +40,7 @@ constexpr long long kStride = 1ll << kLog2Stride;
 constexpr int kLevels = 10;                           // jump polynomials for 2^20 .. 2^29 words: up to 1024 streams per round
 constexpr int kMaxStreams = 1 << kLevels;
 constexpr int kDegree = 19937;
+constexpr int kMaxBits = 10752;                        // set coefficients per polynomial: 19937 / 2 +- a few hundred
 constexpr int kSeqWords = 20608;                      // >= 19937 + 624 + 31: the LDS image of one jump (82 432 bytes)
 constexpr unsigned long long kRoundItems = 1ull << 27;   // samples per generation round (5.1 words each: <= 2.8 GB of words)
 
@@ -57,6 +59,8 @@ __host__ __device__ inline uint32_t mt_temper(uint32_t y) {
 // ---- host: the jump polynomials -------------------------------------------------------------------------------------------
 struct JumpPolys {
     std::vector<uint32_t> poly;   // [kLevels][624]: bit i of level e = coefficient of x^i in x^(2^(20+e)) mod phi
+    std::vector<uint32_t> bits;   // [kLevels][kMaxBits]: the exponents i with a set coefficient, ascending (what the device walks)
+    std::vector<int> nbits;       // [kLevels]
     bool ok = false;
     std::string err;
 };
@@ -181,6 +185,18 @@ inline void compute_jump_polys(JumpPolys &J) {
         for (int k = 1; k < MTN; ++k) same = same && jumped[(size_t)k] == win[(size_t)(head + k) % MTN];
         if (!same) { J.err = "jump polynomial self-check failed"; return; }
     }
+    J.bits.assign((size_t)kLevels * kMaxBits, 0u);
+    J.nbits.assign((size_t)kLevels, 0);
+    for (int e = 0; e < kLevels; ++e) {
+        const uint32_t *pl = J.poly.data() + (size_t)e * MTN;
+        int n = 0;
+        for (int i = 0; i < K; ++i)
+            if ((pl[i >> 5] >> (i & 31)) & 1u) {
+                if (n == kMaxBits) { J.err = "jump polynomial has more set coefficients than expected"; return; }
+                J.bits[(size_t)e * kMaxBits + n++] = (uint32_t)i;
+            }
+        J.nbits[(size_t)e] = n;
+    }
     J.ok = true;
 }
 
@@ -192,34 +208,43 @@ inline const JumpPolys &jump_polys() {
 }
 
 // ---- device: jump --------------------------------------------------------------------------------------------------------
+// One jump = `parts` workgroups: each rebuilds the words its share of the polynomial's set coefficients reaches (the recurrence
+// from the source state, in LDS) and XORs its partial sums into the destination state (zeroed by the host beforehand).
 struct JumpArgs {
     uint32_t *states;        // [S][624]
-    const uint32_t *poly;    // [624] of this level
+    const uint32_t *bits;    // ascending exponents of this level's polynomial
+    int nbits, parts;
     int src_first, dst_first;
 };
 
 __global__ void __launch_bounds__(640) mt_jump_kernel(const JumpArgs a) {
     extern __shared__ uint32_t mt_x[];   // kSeqWords
     const int tid = threadIdx.x;
-    const uint32_t *src = a.states + (size_t)(a.src_first + blockIdx.x) * MTN;
-    uint32_t *dst = a.states + (size_t)(a.dst_first + blockIdx.x) * MTN;
+    const int jump = blockIdx.x / a.parts, part = blockIdx.x - jump * a.parts;
+    const uint32_t *src = a.states + (size_t)(a.src_first + jump) * MTN;
+    uint32_t *dst = a.states + (size_t)(a.dst_first + jump) * MTN;
+    const int j_lo = (int)((long long)a.nbits * part / a.parts), j_hi = (int)((long long)a.nbits * (part + 1) / a.parts);
+    if (j_lo >= j_hi) return;
+    const int need = (int)a.bits[j_hi - 1] + MTN;   // words x[0 .. need) cover this part
     if (tid < MTN) mt_x[tid] = src[tid];
     __syncthreads();
-    for (int base = MTN; base < kSeqWords; base += 224) {   // 224 < 227: every operand was written in an earlier step
+    for (int base = MTN; base < need; base += 224) {   // 224 < 227: every operand was written in an earlier step
         const int i = base + tid;
-        if (tid < 224 && i < kSeqWords) mt_x[i] = mt_next(mt_x[i - 624], mt_x[i - 623], mt_x[i - 227]);
+        if (tid < 224 && i < need) mt_x[i] = mt_next(mt_x[i - 624], mt_x[i - 623], mt_x[i - 227]);
         __syncthreads();
     }
     if (tid < MTN) {
         uint32_t acc = 0;
-        for (int iw = 0; iw < MTN; ++iw) {
-            const uint32_t w = a.poly[iw];   // uniform: a scalar load
-            if (w == 0) continue;
-            const uint32_t *xp = mt_x + iw * 32 + tid;
-#pragma unroll
-            for (int b = 0; b < 32; ++b) acc ^= xp[b] & (0u - ((w >> b) & 1u));
+        const uint32_t *xp = mt_x + tid;
+        int j = j_lo;
+        for (; j + 8 <= j_hi; j += 8) {   // the exponents are uniform: scalar loads
+            const uint32_t p0 = a.bits[j], p1 = a.bits[j + 1], p2 = a.bits[j + 2], p3 = a.bits[j + 3];
+            const uint32_t p4 = a.bits[j + 4], p5 = a.bits[j + 5], p6 = a.bits[j + 6], p7 = a.bits[j + 7];
+            acc ^= xp[p0] ^ xp[p1] ^ xp[p2] ^ xp[p3] ^ xp[p4] ^ xp[p5] ^ xp[p6] ^ xp[p7];
         }
-        dst[tid] = acc;
+        for (; j < j_hi; ++j) acc ^= xp[a.bits[j]];
+        if (a.parts == 1) dst[tid] = acc;
+        else atomicXor(&dst[tid], acc);
     }
 }
 
@@ -230,44 +255,62 @@ struct GenArgs {
     int S;
 };
 
+// Wave-level ordering point for LDS traffic between lanes of ONE wave: the LDS executes a wave's operations in issue order, so only
+// the compiler has to be kept from moving accesses across it.
+__device__ __forceinline__ void mt_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// NSUB sub-steps of 64 words starting at word LO of the 624-word block, in place: every operand is read before any word of the
+// group is written (x[i+1] and x[i+397] of the old block, x[i-227] of the new one, written by an earlier group).
+template <int LO, int NSUB>
+__device__ __forceinline__ void mt_group(uint32_t *x, uint32_t *out_blk, const int lane, const uint32_t remaining) {
+    uint32_t x0[NSUB], x1[NSUB], xm[NSUB];
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+        const int lo = LO + 64 * u, i = lo + lane;
+        if (lo + 64 <= MTN || lane < MTN - lo) {
+            x0[u] = x[i];
+            x1[u] = x[(lo + 64 > MTN && i == MTN - 1) ? 0 : i + 1];                    // x[624] is word 0 of the new block
+            xm[u] = x[lo + 63 < 227 ? i + 397 : lo >= 227 ? i - 227 : i < 227 ? i + 397 : i - 227];
+        }
+    }
+    mt_wave_sync();
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+        const int lo = LO + 64 * u, i = lo + lane;
+        if (lo + 64 <= MTN || lane < MTN - lo) {
+            const uint32_t v = mt_next(x0[u], x1[u], xm[u]);
+            x[i] = v;
+            if ((uint32_t)lo < remaining) out_blk[i] = v;   // uniform: the stream ends on a multiple of 64 words into its last block
+        }
+    }
+    mt_wave_sync();
+}
+
 __global__ void __launch_bounds__(256) mt_generate_kernel(const GenArgs a) {
-    __shared__ uint32_t ring_all[4][1024];
+    __shared__ uint32_t blk_all[4][640];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + wv;
     if (j >= a.S) return;    // no workgroup barrier below: a wave is on its own
-    uint32_t *ring = ring_all[wv];
+    uint32_t *x = blk_all[wv];
     const uint32_t *st = a.states + (size_t)j * MTN;
     for (int i = lane; i < MTN; i += 64) {
         const uint32_t v = st[i];
-        ring[i] = v;
+        x[i] = v;
         if (j == 0) a.xraw[i] = v;
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    uint32_t *out = a.xraw + (size_t)j * kStride;
-    const uint32_t end = 624u + (uint32_t)kStride;
-    for (uint32_t idx0 = 624u; idx0 < end;) {
-        const int ns = end - idx0 >= 192u ? 3 : 1;       // 2^20 / 64 = 3 * 5461 + 1
-        uint32_t x0[3], x1[3], xm[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-            if (u < ns) {
-                const uint32_t i = idx0 + 64u * u + lane;    // LDS operations of one wave execute in order; all operands are >= 227 back
-                x0[u] = ring[(i - 624u) & 1023u];
-                x1[u] = ring[(i - 623u) & 1023u];
-                xm[u] = ring[(i - 227u) & 1023u];
-            }
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-            if (u < ns) {
-                const uint32_t i = idx0 + 64u * u + lane;
-                const uint32_t v = mt_next(x0[u], x1[u], xm[u]);
-                ring[i & 1023u] = v;
-                out[i] = v;
-            }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        idx0 += 64u * ns;
+    mt_wave_sync();
+    uint32_t *out = a.xraw + (size_t)j * kStride + MTN;   // the stream's words [0, kStride)
+    static_assert((kStride % MTN) % 64 == 0, "the last block of a stream must end on a sub-step boundary");
+    for (uint32_t w0 = 0; w0 < (uint32_t)kStride; w0 += MTN) {   // the classic in-place block update, 3 + 3 + 3 + 1 sub-steps
+        const uint32_t remaining = (uint32_t)kStride - w0;
+        uint32_t *ob = out + w0;
+        mt_group<0, 3>(x, ob, lane, remaining);
+        mt_group<192, 3>(x, ob, lane, remaining);
+        mt_group<384, 3>(x, ob, lane, remaining);
+        mt_group<576, 1>(x, ob, lane, remaining);
     }
 }
 
@@ -301,72 +344,75 @@ struct PolarArgs {
     double sigma, punct_val;
 };
 
-constexpr int kPolarSub = 8;   // 256 * 8 attempts per workgroup
+constexpr int kPolarSub = 8;   // a wave takes 64 * 8 consecutive attempts, a workgroup 4 waves
 
 template <int PASS>
 __global__ void __launch_bounds__(256) mt_polar_kernel(const PolarArgs a) {
     __shared__ uint32_t wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long long a0 = (long long)blockIdx.x * (256 * kPolarSub);
-    unsigned long long running = 0, limit = 0;
+    const long long a0 = (long long)blockIdx.x * (256 * kPolarSub) + (long long)wv * (64 * kPolarSub);
+    unsigned long long base = 0, limit = 0;
     if (PASS == 1) {
-        running = a.blockbase[blockIdx.x];
+        base = a.blockbase[blockIdx.x];
         limit = *a.total < a.need ? *a.total : a.need;
         if (a.per_frame) limit -= limit % (unsigned long long)a.per_frame;
-        if (running >= limit) return;
+        if (base >= limit) return;   // uniform over the workgroup
     }
+    double ys[kPolarSub], r2s[kPolarSub];
+    unsigned long long bal[kPolarSub];
     uint32_t mine = 0;
+#pragma unroll
     for (int sub = 0; sub < kPolarSub; ++sub) {
-        const long long at = a0 + sub * 256 + tid;
+        const long long at = a0 + sub * 64 + lane;
         bool ok = false;
-        double y = 0, r2 = 1;
+        ys[sub] = 0; r2s[sub] = 1;
         if (at < a.attempts) {
             const uint32_t *w = a.xraw + a.p + 4 * at;
             const double u0 = mt_canonical(mt_temper(w[0]), mt_temper(w[1]));
             const double u1 = mt_canonical(mt_temper(w[2]), mt_temper(w[3]));
             const double x = 2.0 * u0 - 1.0;               // random.tcc:1821-1825
-            y = 2.0 * u1 - 1.0;
-            r2 = x * x + y * y;
+            const double y = 2.0 * u1 - 1.0;
+            const double r2 = x * x + y * y;
             ok = !(r2 > 1.0 || r2 == 0.0);
+            ys[sub] = y; r2s[sub] = r2;
         }
-        const unsigned long long bal = __ballot(ok);
-        if (PASS == 0) {
-            if (lane == 0) mine += (uint32_t)__popcll(bal);
-        } else {
-            if (lane == 0) wsum[wv] = (uint32_t)__popcll(bal);
-            __syncthreads();
-            unsigned long long g = running + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
-            for (int v = 0; v < wv; ++v) g += wsum[v];
-            const unsigned long long tot = (unsigned long long)wsum[0] + wsum[1] + wsum[2] + wsum[3];
-            __syncthreads();
-            if (ok && g < limit) {
-                if (g + 1 == limit) *a.end_t = a.p + 4 * (at + 1);
-                if (a.out) {
-                    const double mult = sqrt(-2.0 * ldpc_spec::log_glibc(r2) / r2);   // random.tcc:1827
-                    double ret = y * mult;                                               // :1830
-                    ret = ret * 1.0 + 0.0;                                               // :1833 stddev 1, mean 0
-                    if (!a.per_frame) {
-                        a.out[g] = ret;
-                    } else {
-                        const long long f = (long long)(g / (unsigned long long)a.per_frame);
-                        const int i = (int)(g - (unsigned long long)f * (unsigned long long)a.per_frame);
-                        if (f >= a.row_lo && f < a.row_hi) {
-                            const double c = a.tx ? (double)a.tx[(size_t)((a.first_frame + f) % a.ncw) * a.ntx + i] : 0.0;
-                            const double v = -2.0 * (a.sigma * ret + 2.0 * c - 1.0) / (a.sigma * a.sigma);   // bp_simulation.cpp:603 / :610
-                            const int o = a.scatter ? a.scatter[i] : i;                                      // :684
-                            a.out[(f - a.row_lo) * (long long)a.per_frame + o] = o >= a.punct_start ? a.punct_val : v;   // :697-710
-                        }
-                    }
-                }
-            }
-            running += tot;
-            if (running >= limit) return;   // uniform
-        }
+        bal[sub] = __ballot(ok);
+        mine += (uint32_t)__popcll(bal[sub]);
     }
+    if (lane == 0) wsum[wv] = mine;
+    __syncthreads();
     if (PASS == 0) {
-        if (lane == 0) wsum[wv] = mine;
-        __syncthreads();
         if (tid == 0) a.blockcnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        return;
+    }
+    unsigned long long g0 = base;
+    for (int v = 0; v < wv; ++v) g0 += wsum[v];
+    if (g0 >= limit) return;
+#pragma unroll
+    for (int sub = 0; sub < kPolarSub; ++sub) {
+        const bool ok = (bal[sub] >> lane) & 1ull;
+        const unsigned long long g = g0 + (unsigned long long)__popcll(bal[sub] & ((1ull << lane) - 1ull));
+        g0 += (unsigned long long)__popcll(bal[sub]);
+        if (!ok || g >= limit) continue;
+        const long long at = a0 + sub * 64 + lane;
+        if (g + 1 == limit) *a.end_t = a.p + 4 * (at + 1);
+        if (!a.out) continue;
+        const double r2 = r2s[sub];
+        const double mult = sqrt(-2.0 * ldpc_spec::log_glibc(r2) / r2);   // random.tcc:1827
+        double ret = ys[sub] * mult;                                         // :1830
+        ret = ret * 1.0 + 0.0;                                               // :1833 stddev 1, mean 0
+        if (!a.per_frame) {
+            a.out[g] = ret;
+        } else {
+            const long long f = (long long)(g / (unsigned long long)a.per_frame);
+            const int i = (int)(g - (unsigned long long)f * (unsigned long long)a.per_frame);
+            if (f >= a.row_lo && f < a.row_hi) {
+                const double c = a.tx ? (double)a.tx[(size_t)((a.first_frame + f) % a.ncw) * a.ntx + i] : 0.0;
+                const double v = -2.0 * (a.sigma * ret + 2.0 * c - 1.0) / (a.sigma * a.sigma);   // bp_simulation.cpp:603 / :610
+                const int o = a.scatter ? a.scatter[i] : i;                                      // :684
+                a.out[(f - a.row_lo) * (long long)a.per_frame + o] = o >= a.punct_start ? a.punct_val : v;   // :697-710
+            }
+        }
     }
 }
 
@@ -401,7 +447,7 @@ struct DeviceState {
     int pos = 0;                         // next word of d_state to draw (0..624); 0 after every generation round
     long long h_end = 0;                 // staging for the end-offset preset
     uint32_t *d_state = nullptr;         // [624]
-    uint32_t *d_poly = nullptr;          // [kLevels][624]
+    uint32_t *d_bits = nullptr;          // [kLevels][kMaxBits] exponents of the jump polynomials
     uint32_t *d_states = nullptr;        // [cap_streams][624]
     int cap_streams = 0;
     uint32_t *d_xraw = nullptr;          // [cap_words]
@@ -417,7 +463,7 @@ struct DeviceState {
 };
 
 inline void release(DeviceState &m) {
-    void *ptrs[] = {m.d_state, m.d_poly, m.d_states, m.d_xraw, m.d_blockcnt, m.d_blockbase, m.d_total, m.d_end_t, m.d_info, m.d_iters};
+    void *ptrs[] = {m.d_state, m.d_bits, m.d_states, m.d_xraw, m.d_blockcnt, m.d_blockbase, m.d_total, m.d_end_t, m.d_info, m.d_iters};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     m = DeviceState();
 }

@@ -5,14 +5,14 @@ namespace {
 
 int mt_prepare(ldpc_hip_ctx *c) {
     ldpc_mt::DeviceState &m = c->mt;
-    if (m.d_poly) return 0;
+    if (m.d_bits) return 0;
     const ldpc_mt::JumpPolys &J = ldpc_mt::jump_polys();
     if (!J.ok) return fail(LDPC_HIP_EUNSUPPORTED, "mt19937 jump polynomials: %s", J.err.c_str());
     HIP_TRY(hipMalloc(&m.d_state, sizeof(uint32_t) * ldpc_mt::MTN));
     HIP_TRY(hipMalloc(&m.d_total, sizeof(unsigned long long) * 2));
     HIP_TRY(hipMalloc(&m.d_end_t, sizeof(long long) * 2));
-    HIP_TRY(hipMalloc(&m.d_poly, sizeof(uint32_t) * J.poly.size()));
-    HIP_TRY(hipMemcpy(m.d_poly, J.poly.data(), sizeof(uint32_t) * J.poly.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&m.d_bits, sizeof(uint32_t) * J.bits.size()));
+    HIP_TRY(hipMemcpy(m.d_bits, J.bits.data(), sizeof(uint32_t) * J.bits.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_mt::mt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(sizeof(uint32_t) * ldpc_mt::kSeqWords)));
     return 0;
@@ -54,10 +54,13 @@ int mt_round(ldpc_hip_ctx *c, unsigned long long need, ldpc_mt::PolarArgs proto,
         m.cap_blocks = nb;
     }
     HIP_TRY(hipMemcpyAsync(m.d_states, m.d_state, sizeof(uint32_t) * MTN, hipMemcpyDeviceToDevice, st));
+    if (S > 1) HIP_TRY(hipMemsetAsync(m.d_states + MTN, 0, sizeof(uint32_t) * MTN * (size_t)(S - 1), st));   // the jumps XOR into them
+    const JumpPolys &J = jump_polys();
     for (int level = 0; (1ll << level) < S; ++level) {   // stream j + 2^level from stream j, j < 2^level
         const long long have = 1ll << level, cnt = have < S - have ? have : S - have;
-        JumpArgs ja{m.d_states, m.d_poly + (size_t)level * MTN, 0, (int)have};
-        hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)cnt), dim3(640), sizeof(uint32_t) * kSeqWords, st, ja);
+        const int parts = cnt >= 256 ? 1 : cnt >= 128 ? 2 : cnt >= 64 ? 4 : 8;   // few jumps: spread each over several CUs
+        JumpArgs ja{m.d_states, m.d_bits + (size_t)level * kMaxBits, J.nbits[(size_t)level], parts, 0, (int)have};
+        hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(cnt * parts)), dim3(640), sizeof(uint32_t) * kSeqWords, st, ja);
     }
     GenArgs ga{m.d_states, m.d_xraw, (int)S};
     hipLaunchKernelGGL(mt_generate_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, ga);

@@ -1,0 +1,81 @@
+"""Throughput of the exact-replay path (upstream's own mt19937 / normal_distribution noise continued on the device):
+samples/s of the generator alone, frames/s of noise -> decode -> count, and the C++ harness end to end (device noise vs host noise).
+Usage: python tools/time_exact.py [--frames N] [--host-frames N]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=400000)
+    ap.add_argument("--host-frames", type=int, default=8000)
+    ap.add_argument("--snr", type=float, default=2.0)
+    args = ap.parse_args()
+    import torch
+    import ldpc_lib_amd
+    from ldpc_testlib import MS_DEC, load_base_matrix, relift
+    from test_mt_replay import seeded_state, _compat
+    H = relift(load_base_matrix(), 64)
+    out = {}
+    with ldpc_lib_amd.LdpcHip(MS_DEC, H, 64) as dec:
+        key, pos = seeded_state(1)
+        dec.mt_set_state(key, pos)
+        n = 1 << 27
+        buf = torch.empty(n, dtype=torch.float64, device="cuda")
+        dec.mt_normal(1 << 20, out=buf)   # warm-up: polynomials, buffers
+        dec.mt_normal(n, out=buf)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        dec.mt_normal(n, out=buf)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        out["generator"] = {"samples": n, "seconds": dt, "samples_per_s": n / dt, "frames_per_s_at_N2048": n / dt / 2048}
+        del buf
+        for B in (4096, 65536):
+            dec.mt_frames(args.snr, 50, B)
+            t = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                info, its = dec.mt_frames(args.snr, 50, B)
+            dt = (time.perf_counter() - t) / reps
+            out[f"mt_frames_B{B}"] = {"snr_db": args.snr, "seconds": dt, "frames_per_s": B / dt, "fer": float((info != 0).mean()),
+                                      "mean_iters": float(np.abs(its).mean())}
+        # the same decode on resident LLRs, for the share of the noise
+        llr = dec.mt_llr(args.snr, 65536)
+        torch.cuda.synchronize()
+        dec.decode(llr, 50)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            dec.decode(llr, 50)
+        torch.cuda.synchronize()
+        out["decode_only_B65536"] = {"seconds": (time.perf_counter() - t) / 3, "frames_per_s": 65536 / ((time.perf_counter() - t) / 3)}
+        del llr
+    lib = _compat(ldpc_lib_amd)
+    Hc = np.ascontiguousarray(H, dtype=np.int32)
+    for noise, nfr in (("device", args.frames), ("host", args.host_frames)):
+        os.environ["LDPC_HIP_EXACT_NOISE"] = noise
+        res = (C.c_double * 7)()
+        nxt = C.c_uint()
+        t = time.perf_counter()
+        rc = lib.ldpc_bp_simulation_exact_perm(16, 32, Hc.ctypes.data, 64, 50, 10**9, nfr, args.snr, 1.0, MS_DEC, 0, 0, 128, 1, 0, 1, 0,
+                                               C.addressof(res), C.addressof(nxt))
+        dt = time.perf_counter() - t
+        assert rc == 0
+        out[f"harness_{noise}_noise"] = {"frames": int(res[5]), "seconds": dt, "frames_per_s": res[5] / dt, "fer": res[1], "errored": int(res[3]),
+                                         "rng_next": nxt.value}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
