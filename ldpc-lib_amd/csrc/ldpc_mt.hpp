@@ -397,6 +397,13 @@ __global__ void __launch_bounds__(256) mt_polar_kernel(const PolarArgs a) {
         const long long at = a0 + sub * 64 + lane;
         if (g + 1 == limit) *a.end_t = a.p + 4 * (at + 1);
         if (!a.out) continue;
+        long long f = 0;
+        int i = 0;
+        if (a.per_frame) {   // a shard only evaluates the samples of its own frames
+            f = (long long)(g / (unsigned long long)a.per_frame);
+            i = (int)(g - (unsigned long long)f * (unsigned long long)a.per_frame);
+            if (f < a.row_lo || f >= a.row_hi) continue;
+        }
         const double r2 = r2s[sub];
         const double mult = sqrt(-2.0 * ldpc_spec::log_glibc(r2) / r2);   // random.tcc:1827
         double ret = ys[sub] * mult;                                         // :1830
@@ -404,14 +411,10 @@ __global__ void __launch_bounds__(256) mt_polar_kernel(const PolarArgs a) {
         if (!a.per_frame) {
             a.out[g] = ret;
         } else {
-            const long long f = (long long)(g / (unsigned long long)a.per_frame);
-            const int i = (int)(g - (unsigned long long)f * (unsigned long long)a.per_frame);
-            if (f >= a.row_lo && f < a.row_hi) {
-                const double c = a.tx ? (double)a.tx[(size_t)((a.first_frame + f) % a.ncw) * a.ntx + i] : 0.0;
-                const double v = -2.0 * (a.sigma * ret + 2.0 * c - 1.0) / (a.sigma * a.sigma);   // bp_simulation.cpp:603 / :610
-                const int o = a.scatter ? a.scatter[i] : i;                                      // :684
-                a.out[(f - a.row_lo) * (long long)a.per_frame + o] = o >= a.punct_start ? a.punct_val : v;   // :697-710
-            }
+            const double c = a.tx ? (double)a.tx[(size_t)((a.first_frame + f) % a.ncw) * a.ntx + i] : 0.0;
+            const double v = -2.0 * (a.sigma * ret + 2.0 * c - 1.0) / (a.sigma * a.sigma);   // bp_simulation.cpp:603 / :610
+            const int o = a.scatter ? a.scatter[i] : i;                                      // :684
+            a.out[(f - a.row_lo) * (long long)a.per_frame + o] = o >= a.punct_start ? a.punct_val : v;   // :697-710
         }
     }
 }

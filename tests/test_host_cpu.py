@@ -26,7 +26,7 @@ def test_build_entry_point_and_abi_exports():
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), f"{n} declared in ldpc_hip.h but not exported"
-    assert lib.ldpc_hip_abi_version() == 2
+    assert lib.ldpc_hip_abi_version() == 3
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

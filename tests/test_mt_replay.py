@@ -216,3 +216,90 @@ def test_harness_on_the_device_with_an_interleaver(L, torch, monkeypatch, perm_t
                                        inv.ctypes.data_as(c_int_p), C.byref(res), None) == 0
     assert (out[2], out[3], out[4], out[5]) == (res.nse, res.nde, res.nue, res.experiment)
     assert out[0] == res.ber and out[1] == res.fer and nxt.value == res.rng_next
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("modulation,punct,perm,with_codewords,dec_id", [
+    (0, 0, 0, False, SP_DEC),      # probability-type decoder: nothing punctured, plain
+    (1, 2, 3, True, MS_DEC),       # QAM4 sigma (:449), two punctured blocks (0.5, :700), block interleaver, real codewords
+    (0, 1, 1, True, TASP_DEC),     # out_type 1 puncturing value 0
+])
+def test_device_llr_chain_options(L, torch, modulation, punct, perm, with_codewords, dec_id):
+    """mt_llr with every option of the frame loop == the same chain composed in numpy from the host's samples:
+    y[i] = buffer[inverse[i]], buffer[j] = -2 (sigma g_j + 2 c_j - 1) / sigma^2, c = codeword through the direct map, tail punctured."""
+    from ldpc_lib_amd.binding import build_interleaver, encode
+    M, frames, seed, snr = 64, 50, 12, 2.2
+    H = relift(load_base_matrix(), M)
+    rh, nh = H.shape
+    N = nh * M
+    g = oracle_gaussians(seed, frames * N).reshape(frames, N)
+    bitrate = (nh - rh) / (nh - punct)
+    if modulation == 0:
+        sigma = np.sqrt(np.power(10.0, -snr / 10) / 2 / bitrate)
+    else:
+        sigma = np.sqrt(np.power(10.0, -snr / 10.0) / (2 * bitrate * 1 * 2) * (2.0 * (4 - 1.0) / 3.0))
+    rng = np.random.default_rng(5)
+    ncw = 3
+    cws = np.stack([encode(H, M, rng.integers(0, 2, (nh - rh) * M, dtype=np.uint8)) for _ in range(ncw)]) if with_codewords else None
+    direct = inverse = np.arange(N)
+    if perm:
+        direct, inverse = build_interleaver(H, M, perm, 1, 64, 1)
+    want = np.empty((frames, N))
+    for f in range(frames):
+        c = cws[f % ncw][direct].astype(np.float64) if with_codewords else np.zeros(N)
+        buf = -2.0 * (sigma * g[f] + 2.0 * c - 1.0) / (sigma * sigma)
+        y = buf[inverse]
+        if punct:
+            y[N - M * punct:] = 0.0 if dec_id in (SP_DEC, TASP_DEC) else 0.5
+        want[f] = y
+    key, pos = seeded_state(seed)
+    with L.LdpcHip(dec_id, H, M) as dec:
+        if perm:
+            dec.set_interleaver(perm, 64, 1)
+        if with_codewords:
+            dec.set_codewords(cws)
+        dec.mt_set_state(key, pos)
+        got = torch.cat([dec.mt_llr(snr, 20, modulation=modulation, punctured_blocks=punct),
+                         dec.mt_llr(snr, frames - 20, modulation=modulation, punctured_blocks=punct)]).cpu().numpy()
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_device_generator_soak(L, torch):
+    """random seeds, start positions inside the block and call splits (single words up to several streams)"""
+    H = relift(load_base_matrix(), 1)
+    rng = np.random.default_rng(2024)
+    with L.LdpcHip(MS_DEC, H, 1) as dec:
+        for case in range(12):
+            seed = int(rng.integers(1, 2**31))
+            burn = int(rng.integers(0, 3000))
+            counts = [int(c) for c in rng.choice([1, 2, 3, 63, 64, 65, 1000, 4097, 300_000, 1_500_000], size=int(rng.integers(1, 6)))]
+            want = oracle_gaussians(seed, sum(counts), burn)
+            key, pos = seeded_state(seed)
+            if burn:
+                bg = np.random.MT19937()
+                s = bg.state
+                s["state"]["key"] = key; s["state"]["pos"] = pos
+                bg.state = s
+                bg.random_raw(burn)
+                key, pos = bg.state["state"]["key"].astype(np.uint32), int(bg.state["state"]["pos"])
+            dec.mt_set_state(key, pos)
+            got = torch.cat([dec.mt_normal(c) for c in counts]).cpu().numpy()
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (case, seed, burn, counts)
+
+
+@pytest.mark.gpu
+def test_generator_needs_a_state_and_sane_arguments(L, torch):
+    H = relift(load_base_matrix(), 64)
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        with pytest.raises(L.LdpcHipError):
+            dec.mt_normal(10)                       # no state loaded
+        key, pos = seeded_state(1)
+        with pytest.raises(L.LdpcHipError):
+            dec.mt_set_state(key, 625)
+        dec.mt_set_state(key, pos)
+        with pytest.raises(L.LdpcHipError):
+            dec.mt_llr(2.0, 4, modulation=2)        # QAM16+: nothing to replay (SURVEY Appendix B Q5/Q6)
+        assert dec.mt_normal(0).numel() == 0
+        info, its = dec.mt_frames(2.0, 50, 0)
+        assert info.shape == (0,) and its.shape == (0,)
