@@ -253,6 +253,7 @@ struct GenArgs {
     const uint32_t *states;   // [S][624]
     uint32_t *xraw;           // [624 + S * kStride] untempered words; stream j writes [624 + j*kStride, 624 + (j+1)*kStride)
     int S;
+    long long words;          // words wanted behind the first 624 (a multiple of 64): the last stream stops there
 };
 
 // Wave-level ordering point for LDS traffic between lanes of ONE wave: the LDS executes a wave's operations in issue order, so only
@@ -304,8 +305,10 @@ __global__ void __launch_bounds__(256) mt_generate_kernel(const GenArgs a) {
     mt_wave_sync();
     uint32_t *out = a.xraw + (size_t)j * kStride + MTN;   // the stream's words [0, kStride)
     static_assert((kStride % MTN) % 64 == 0, "the last block of a stream must end on a sub-step boundary");
-    for (uint32_t w0 = 0; w0 < (uint32_t)kStride; w0 += MTN) {   // the classic in-place block update, 3 + 3 + 3 + 1 sub-steps
-        const uint32_t remaining = (uint32_t)kStride - w0;
+    const long long left = a.words - (long long)j * kStride;
+    const uint32_t nwords = left >= kStride ? (uint32_t)kStride : left > 0 ? (uint32_t)left : 0u;   // a short round stops early
+    for (uint32_t w0 = 0; w0 < nwords; w0 += MTN) {   // the classic in-place block update, 3 + 3 + 3 + 1 sub-steps
+        const uint32_t remaining = nwords - w0;
         uint32_t *ob = out + w0;
         mt_group<0, 3>(x, ob, lane, remaining);
         mt_group<192, 3>(x, ob, lane, remaining);

@@ -43,7 +43,10 @@ int mt_round(ldpc_hip_ctx *c, unsigned long long need, ldpc_mt::PolarArgs proto,
         HIP_TRY(hipMalloc(&m.d_xraw, sizeof(uint32_t) * words));
         m.cap_words = words;
     }
-    const long long attempts = ((long long)S * kStride - m.pos) / 4;   // the last 624 words stay unread: they are the next state
+    long long attempts = ((long long)S * kStride - m.pos) / 4;   // the last 624 words stay unread: they are the next state
+    if (attempts > A) attempts = A;                              // a short round neither generates nor scans a whole stream
+    long long gen_words = (m.pos + 4 * attempts + 63) / 64 * 64;  // words behind the first 624 that the round reads or adopts
+    if (gen_words > (long long)S * kStride) gen_words = (long long)S * kStride;
     const long long nb = (attempts + 256 * kPolarSub - 1) / (256 * kPolarSub);
     if (nb > m.cap_blocks) {
         if (m.d_blockcnt) (void)hipFree(m.d_blockcnt);
@@ -62,7 +65,7 @@ int mt_round(ldpc_hip_ctx *c, unsigned long long need, ldpc_mt::PolarArgs proto,
         JumpArgs ja{m.d_states, m.d_bits + (size_t)level * kMaxBits, J.nbits[(size_t)level], parts, 0, (int)have};
         hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(cnt * parts)), dim3(640), sizeof(uint32_t) * kSeqWords, st, ja);
     }
-    GenArgs ga{m.d_states, m.d_xraw, (int)S};
+    GenArgs ga{m.d_states, m.d_xraw, (int)S, gen_words};
     hipLaunchKernelGGL(mt_generate_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, ga);
     proto.xraw = m.d_xraw; proto.p = m.pos; proto.attempts = attempts;
     proto.blockcnt = m.d_blockcnt; proto.blockbase = m.d_blockbase; proto.total = m.d_total; proto.need = need; proto.end_t = m.d_end_t;

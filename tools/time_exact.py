@@ -74,6 +74,31 @@ def main():
         assert rc == 0
         out[f"harness_{noise}_noise"] = {"frames": int(res[5]), "seconds": dt, "frames_per_s": res[5] / dt, "fer": res[1], "errored": int(res[3]),
                                          "rng_next": nxt.value}
+    # short runs, as the code search issues them (one bp_simulation call per candidate code and SNR): whole-call latency
+    from ldpc_testlib import TASP_DEC
+    short = {}
+    for name, dec_id, Ms, maxit, n_fe, n_exp, snr in (("cfg2_4001_frames", MS_DEC, 64, 50, 10**9, 4000, 2.0),
+                                                       ("shipped_search_scenario_tasp_m126_50_errors", TASP_DEC, 126, 15, 50, 10**8, 1.7),
+                                                       ("cfg1_m1_2001_frames", MS_DEC, 1, 20, 10**9, 2000, 4.0)):
+        Hs = np.ascontiguousarray(relift(load_base_matrix(), Ms), dtype=np.int32)
+        row = {}
+        for noise in ("device", "host"):
+            os.environ["LDPC_HIP_EXACT_NOISE"] = noise
+            best = None
+            for rep in range(3):
+                res = (C.c_double * 7)()
+                nxt = C.c_uint()
+                t = time.perf_counter()
+                rc = lib.ldpc_bp_simulation_exact_perm(16, 32, Hs.ctypes.data, Ms, maxit, n_fe, n_exp, snr, 1.0, dec_id, 0, 0, 128, 1, 0, 1, 0,
+                                                       C.addressof(res), C.addressof(nxt))
+                dt = time.perf_counter() - t
+                assert rc == 0
+                best = dt if best is None or dt < best else best
+            row[noise] = {"seconds": best, "frames": int(res[5]), "errored": int(res[3]), "rng_next": nxt.value}
+        assert row["device"]["rng_next"] == row["host"]["rng_next"] and row["device"]["errored"] == row["host"]["errored"]
+        row["speedup"] = row["host"]["seconds"] / row["device"]["seconds"]
+        short[name] = row
+    out["whole_call_latency_best_of_3"] = short
     print(json.dumps(out, indent=1))
 
 
