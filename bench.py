@@ -86,7 +86,7 @@ def mt19937_seeded(seed):
     return st.astype(np.uint32), 624
 
 
-def exact_replay_block(ldpc_lib_amd, H, device, torch):
+def exact_replay_block(ldpc_lib_amd, H, device, torch, pmc=None):
     """The exact-replay path (include/ldpc/bp_simulation.h's default): upstream's own noise stream -- std::mt19937 seed 1 through a
     fresh std::normal_distribution per sample, commons_portable.cpp:140,174-178 -- continued ON THE DEVICE (csrc/ldpc_mt.hpp), then
     decode and count.  First the headline configuration's own run (4001 frames at 2.0 dB, 170 errored with
@@ -126,6 +126,10 @@ def exact_replay_block(ldpc_lib_amd, H, device, torch):
         del buf
     words = 4.0 / (np.pi / 4.0)             # mt19937 words per accepted polar attempt
     bytes_per_sample = 3 * 4.0 * words + 8  # words written once, read by the count and the emit pass; one fp64 sample out
+    traffic = None
+    p = (pmc or {}).get("exact_replay_generator")
+    if p and p.get("samples") == n:
+        traffic = (2.0 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0   # per round of n samples, FETCH_SIZE x2 per the gfx950 calibration
     return {
         "what": "upstream's mt19937 + normal_distribution noise stream continued on the device -> min-sum decode -> count "
                 "(ldpc_hip_mt_frames), (2048,1024), 50 it, Eb/N0 2.0 dB, seed 1: bit-identical to the frame-by-frame host loop",
@@ -133,7 +137,9 @@ def exact_replay_block(ldpc_lib_amd, H, device, torch):
         "value": steps * FRAMES_PER_GPU / el, "unit": "frames/s", "frames_per_step": FRAMES_PER_GPU, "steps": steps,
         "fer": nerr / (steps * FRAMES_PER_GPU), "mean_iters_per_frame": nit / (steps * FRAMES_PER_GPU),
         "generator": {"samples_per_s": n / gen_s, "samples": n, "bound": "hbm", "algorithmic_bytes_per_sample": bytes_per_sample,
-                      "achieved_GBs": n / gen_s * bytes_per_sample / 1e9, "frac": n / gen_s * bytes_per_sample / 1e9 / HBM_PEAK_GBS},
+                      "achieved_GBs": n / gen_s * bytes_per_sample / 1e9, "frac": n / gen_s * bytes_per_sample / 1e9 / HBM_PEAK_GBS,
+                      "traffic": traffic, "traffic_unit": "HBM bytes per 2^27-sample round (PMC)",
+                      "hbm_physical_frac": traffic / gen_s / 1e9 / HBM_PEAK_GBS if traffic else None},
     }
 
 
@@ -415,7 +421,7 @@ def main():
                 cfgs[c["key"]] = {"workload": c["what"], "error": repr(ex)}
         out["configs"] = cfgs
         try:
-            out["exact_replay"] = exact_replay_block(ldpc_lib_amd, H, local, torch)
+            out["exact_replay"] = exact_replay_block(ldpc_lib_amd, H, local, torch, pmc)
         except Exception as ex:
             out["exact_replay"] = {"error": repr(ex)}
 

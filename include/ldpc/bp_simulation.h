@@ -152,7 +152,12 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
     for (int i = 0; i < b; ++i) for (int j = 0; j < c; ++j) hd[(size_t)i * c + j] = (int16_t)H(i, j);  // :359-361
     ldpc_hip_multi *ctx = nullptr;   // one DEC_STATE per GPU; the batch of a round is cut into contiguous slices
     if (devices.empty()) Env::fail("bp_simulation: empty device list");
-    if (ldpc_hip_open_multi(decoder_type, b, c, M, hd.data(), devices.data(), (int)devices.size(), &ctx) != 0) Env::fail(ldpc_hip_last_error());  // :353-355
+    // a code search calls this once per candidate matrix (main_good_code_search.cpp:320): never wait for hiprtc here, start on the
+    // table-driven / shape-unlimited kernel and move to the code-specialised instance when the background compile delivers it
+    const int jit_before = ldpc_hip_set_jit_mode(2);
+    const int open_rc = ldpc_hip_open_multi(decoder_type, b, c, M, hd.data(), devices.data(), (int)devices.size(), &ctx);  // :353-355
+    if (jit_before >= 0) (void)ldpc_hip_set_jit_mode(jit_before);
+    if (open_rc != 0) Env::fail(ldpc_hip_last_error());
     max_batch *= (long long)devices.size();
 
     int out_type;  // :451-466
@@ -312,7 +317,10 @@ std::pair<double, double> bp_simulation_throughput_t(int q_mod, Mat const &H, in
     std::vector<int16_t> hd((size_t)b * c);
     for (int i = 0; i < b; ++i) for (int j = 0; j < c; ++j) hd[(size_t)i * c + j] = (int16_t)H(i, j);
     ldpc_hip_multi *m = nullptr;
-    if (ldpc_hip_open_multi(decoder_type, b, c, M, hd.data(), devices.data(), (int)devices.size(), &m) != 0) Env::fail(ldpc_hip_last_error());
+    const int jit_before = ldpc_hip_set_jit_mode(2);   // as in exact-replay mode: no waiting for hiprtc
+    const int open_rc = ldpc_hip_open_multi(decoder_type, b, c, M, hd.data(), devices.data(), (int)devices.size(), &m);
+    if (jit_before >= 0) (void)ldpc_hip_set_jit_mode(jit_before);
+    if (open_rc != 0) Env::fail(ldpc_hip_last_error());
     if (ldpc_hip_multi_set_interleaver(m, permutation_type, permutation_block, permutation_inter) != 0) Env::fail(ldpc_hip_last_error());
     if (ncw > 0 && ldpc_hip_multi_set_codewords(m, codewords, ncw) != 0) Env::fail(ldpc_hip_last_error());
     const int nsh = (int)devices.size();

@@ -62,6 +62,14 @@ int ldpc_hip_edges(const ldpc_hip_ctx *ctx);      /* non-empty circulants */
 int ldpc_hip_hard_words(const ldpc_hip_ctx *ctx); /* ceil(N/32): uint32 words per frame of packed hard bits */
 /* Name of the decode kernel this context launches (code-specialised AOT / hiprtc instance, table-driven, generic). */
 const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *ctx);
+/* Where ldpc_hip_open gets the code-specialised kernel of a base matrix that has no ahead-of-time instance (process-wide default; the
+ * environment variable LDPC_HIP_JIT = 0 / sync / async overrides it): 0 never (table-driven or shape-unlimited kernels only),
+ * 1 hiprtc inside ldpc_hip_open (seconds per new code, milliseconds from the on-disk cache) [default], 2 in the background: the
+ * context starts on its table-driven / shape-unlimited kernel and moves to the instance at the first launch after it is ready --
+ * every tier returns identical bits, so a run may change tier in flight.  Mode 2 is what a code search wants (upstream's
+ * main_good_code_search.cpp:320 calls bp_simulation once per candidate matrix); ldpc::bp_simulation_t selects it.
+ * Returns the previous mode, or LDPC_HIP_EINVAL. */
+int ldpc_hip_set_jit_mode(int mode);
 /* Name of the kernel the last ldpc_hip_decode_dev call on this context launched.  It differs from ldpc_hip_kernel_name only
  * for IMS_DEC with parameters beyond int8 (MS_DBITS > 8, MS_QBITS > 8 or alpha > 1), which run on the table-driven int32 kernel. */
 const char *ldpc_hip_last_launch(const ldpc_hip_ctx *ctx);

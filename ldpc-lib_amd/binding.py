@@ -115,6 +115,7 @@ def load_library():
     lib.ldpc_hip_simulate_multi.argtypes = [vp, f64, i32, i32, i32, f64, u64, i64, i64, i64, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.ldpc_hip_frames_multi.argtypes = [vp, f64, i32, i32, i32, f64, u64, i64, i64, i64, vp, vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.ldpc_hip_decode_host_multi.argtypes = [vp, vp, i64, i32, i32, f64, vp, vp, i32]
+    lib.ldpc_hip_set_jit_mode.argtypes = [i32]
     lib.ldpc_hip_mt_jump_host.argtypes = [vp, i32, vp]
     lib.ldpc_hip_mt_set_state.argtypes = [vp, vp, i32]
     lib.ldpc_hip_mt_get_state.argtypes = [vp, vp, C.POINTER(i32)]
@@ -155,7 +156,14 @@ class LdpcHip:
         self.R = self.lib.ldpc_hip_r(h)
         self.edges = self.lib.ldpc_hip_edges(h)
         self.hard_words = self.lib.ldpc_hip_hard_words(h)
-        self.kernel_name = self.lib.ldpc_hip_kernel_name(h).decode()
+        self._kernel_name = self.lib.ldpc_hip_kernel_name(h).decode()
+
+    @property
+    def kernel_name(self):
+        """Kernel this context launches; with LDPC_HIP_JIT=async it changes once the background hiprtc instance is ready."""
+        if getattr(self, "h", None):
+            self._kernel_name = self.lib.ldpc_hip_kernel_name(self.h).decode()
+        return self._kernel_name
 
     def close(self):
         if getattr(self, "h", None):

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <memory>
 #include <string>
 #include <type_traits>
@@ -198,6 +199,9 @@ struct ldpc_hip_ctx {
     int spec_threads = 64;
     int spec_frames_per_block = 1;
     size_t spec_lds = 0;
+    std::shared_ptr<ldpc_jit::Job> jit_job;   // LDPC_HIP_JIT=async: the instance is being compiled in the background; until it is
+    std::string jit_name;                     // ready the table-driven / shape-unlimited tier runs (identical bits)
+    bool global_is_fallback = false;
     std::string kernel_name;  // what this context launches (ldpc_hip_kernel_name)
     std::string generic_name; // the table-driven kernel of this decoder, if one serves this code shape
     const char *last_launch = "";  // ldpc_hip_last_launch
@@ -242,6 +246,31 @@ struct ldpc_hip_ctx {
 };
 
 namespace {
+
+std::atomic<int> g_jit_mode{1};   // ldpc_hip_set_jit_mode: 0 never, 1 compile inside ldpc_hip_open, 2 compile in the background
+
+int jit_mode_effective() {
+    if (const char *e = getenv("LDPC_HIP_JIT")) {   // the environment wins
+        const std::string v(e);
+        if (v == "async" || v == "2") return 2;
+        if (v == "sync") return 1;
+        return atoi(e) != 0 ? 1 : 0;
+    }
+    return g_jit_mode.load();
+}
+
+// moves a context onto its code-specialised instance once the background compile has delivered it
+void adopt_jit(ldpc_hip_ctx *c) {
+    if (!c->jit_job) return;
+    const int st = c->jit_job->state.load(std::memory_order_acquire);
+    if (st == 0) return;
+    if (st == 1) {
+        c->spec_jit = c->jit_job->kernel;
+        c->kernel_name = c->jit_name;
+        if (c->global_is_fallback) c->global_tier = false;
+    }
+    c->jit_job.reset();
+}
 
 int set_device(const ldpc_hip_ctx *c) {
     HIP_TRY(hipSetDevice(c->device));
@@ -461,6 +490,11 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
     c->have_generic = have_generic;
     if (have_generic) c->generic_name = c->kernel_name;
 
+    bool all_cw2 = true;   // upstream's all-columns-of-weight-2 branch of decoder 2 (decoders.cpp:2431-2480) is not built
+    for (int k = 0; k < nh; ++k) all_cw2 = all_cw2 && (t.col_start[k + 1] - t.col_start[k] == 2);
+    const bool can_global = decoder_id == LDPC_HIP_BP_DEC || decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || decoder_id == LDPC_HIP_SP_DEC || decoder_id == LDPC_HIP_IMS_DEC ||
+                            (decoder_id == LDPC_HIP_TASP_DEC && t.min_rw >= 2) || (decoder_id == LDPC_HIP_ASP_DEC && t.min_rw >= 2 && !all_cw2);
+
     // ---- code-specialised instance: ahead of time for the shipped example code, hiprtc for anything else
     const SpecPlan plan = plan_spec(decoder_id, t);
     std::string why_not = plan.body ? "" : "this code shape has no code-specialised kernel";
@@ -472,21 +506,34 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
                 c->kernel_name = std::string(inst.name) + " (ahead of time)";
                 break;
             }
-        const char *jenv = getenv("LDPC_HIP_JIT");
-        if (!c->spec_aot && (!jenv || atoi(jenv) != 0)) {
-            c->spec_jit = ldpc_jit::get(device, plan.body, t.rows(), nh, M, why_not);
+        const int jit_mode = jit_mode_effective();
+        const char *fg = getenv("LDPC_HIP_FORCE_GLOBAL");
+        const bool forced_global = fg && atoi(fg) != 0;
+        if (!c->spec_aot && jit_mode != 0 && !forced_global) {
+            // background compile only where another HIP tier can serve the first launches
+            const bool has_fallback = have_generic || can_global;
+            if (jit_mode == 2 && has_fallback) {
+                c->spec_jit = ldpc_jit::get(device, plan.body, t.rows(), nh, M, why_not, /*compile=*/false);   // process or disk cache
+                if (!c->spec_jit) {
+                    auto job = std::make_shared<ldpc_jit::Job>();
+                    job->device = device; job->nh = nh; job->M = M; job->body = plan.body; job->rows = t.rows();
+                    ldpc_jit::Worker::instance().submit(job);
+                    c->jit_job = job;
+                    c->jit_name = std::string(plan.body) + " instance (hiprtc)";
+                    why_not = "its hiprtc instance is being compiled in the background";
+                }
+            } else {
+                c->spec_jit = ldpc_jit::get(device, plan.body, t.rows(), nh, M, why_not);
+            }
             if (c->spec_jit) c->kernel_name = std::string(plan.body) + " instance (hiprtc)";
         } else if (!c->spec_aot) {
-            why_not = "LDPC_HIP_JIT=0";
+            why_not = forced_global ? "LDPC_HIP_FORCE_GLOBAL" : "LDPC_HIP_JIT=0";
         }
     }
     const char *genv = getenv("LDPC_HIP_FORCE_GLOBAL");   // tests: run the shape-unlimited tier on shapes the resident kernels take
-    bool all_cw2 = true;   // upstream's all-columns-of-weight-2 branch of decoder 2 (decoders.cpp:2431-2480) is not built
-    for (int k = 0; k < nh; ++k) all_cw2 = all_cw2 && (t.col_start[k + 1] - t.col_start[k] == 2);
-    const bool can_global = decoder_id == LDPC_HIP_BP_DEC || decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || decoder_id == LDPC_HIP_SP_DEC || decoder_id == LDPC_HIP_IMS_DEC ||
-                            (decoder_id == LDPC_HIP_TASP_DEC && t.min_rw >= 2) || (decoder_id == LDPC_HIP_ASP_DEC && t.min_rw >= 2 && !all_cw2);
     if (can_global && ((genv && atoi(genv) != 0) || (!c->spec_aot && !c->spec_jit && !have_generic))) {
         c->global_tier = true;
+        c->global_is_fallback = c->jit_job != nullptr;   // until the background instance arrives
         c->spec_aot = nullptr; c->spec_jit = nullptr;
         c->kernel_name = decoder_id == LDPC_HIP_MS_DEC ? "ms_global_kernel" : decoder_id == LDPC_HIP_LMS_DEC ? "lms_global_kernel" : decoder_id == LDPC_HIP_IMS_DEC ? "ims_global_kernel" : decoder_id == LDPC_HIP_ASP_DEC ? "asp_global_kernel" : decoder_id == LDPC_HIP_BP_DEC ? "bp_global_kernel" :
                          decoder_id == LDPC_HIP_SP_DEC ? "sp_global_kernel" : "tasp_global_kernel";
@@ -500,7 +547,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
                         "%d block columns, row weight %d, M <= 512, 160 KiB LDS), no code-specialised instance: %s; the shape-unlimited "
                         "tier serves every built decoder; decoders 2 and 7 need row weights >= 2, decoder 2 a block column of weight != 2",
                         decoder_id, rh, nh, M, kRHM, kNHM, kRWM, why_not.c_str());
-        if (plan.body && c->variant >= 2)
+        if (plan.body && c->variant >= 2 && !c->jit_job)
             fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", why_not.c_str(), c->kernel_name.c_str());
     }
 
@@ -524,6 +571,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
 
 void ldpc_hip_close(ldpc_hip_ctx *c) {
     if (!c) return;
+    if (c->jit_job) c->jit_job->cancelled.store(true);   // not compiled yet: drop it
     (void)hipSetDevice(c->device);
     free_workspace(c);
     if (c->d_row_start) (void)hipFree(c->d_row_start);
@@ -550,7 +598,16 @@ int ldpc_hip_n(const ldpc_hip_ctx *c) { return c ? c->N : 0; }
 int ldpc_hip_r(const ldpc_hip_ctx *c) { return c ? c->R : 0; }
 int ldpc_hip_edges(const ldpc_hip_ctx *c) { return c ? c->ne : 0; }
 int ldpc_hip_hard_words(const ldpc_hip_ctx *c) { return c ? c->hard_words : 0; }
-const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *c) { return c ? c->kernel_name.c_str() : ""; }
+const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *c) {
+    if (!c) return "";
+    adopt_jit(const_cast<ldpc_hip_ctx *>(c));
+    return c->kernel_name.c_str();
+}
+
+int ldpc_hip_set_jit_mode(int mode) {
+    if (mode < 0 || mode > 2) return fail(LDPC_HIP_EINVAL, "ldpc_hip_set_jit_mode: 0 (never), 1 (inside ldpc_hip_open) or 2 (in the background)");
+    return g_jit_mode.exchange(mode);
+}
 const char *ldpc_hip_last_launch(const ldpc_hip_ctx *c) { return c ? c->last_launch : ""; }
 
 int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int maxiter, double alpha,
@@ -564,6 +621,7 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
     if (maxiter < 1) return fail(LDPC_HIP_EINVAL, "ldpc_hip_decode_dev: maxiter must be >= 1 (got %d)", maxiter);
     if (int rc = set_device(c)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
+    adopt_jit(c);
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->prof) {

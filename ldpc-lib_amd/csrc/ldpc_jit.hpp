@@ -12,14 +12,19 @@
 #include <unistd.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <fstream>
 #include <iterator>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace ldpc_jit {
@@ -45,6 +50,8 @@ struct Rtc {
 inline Rtc *rtc(std::string &err) {
     static Rtc r;
     static bool tried = false;
+    static std::mutex rtc_mu;
+    std::lock_guard<std::mutex> rtc_lk(rtc_mu);
     if (tried) { if (!r.lib) err = "hiprtc not available"; return r.lib ? &r : nullptr; }
     tried = true;
     std::vector<std::string> names;
@@ -106,21 +113,28 @@ inline std::string this_library_dir() {
 
 // Returns the cached or freshly compiled kernel for (device, decoder body, rows, M); nullptr + err on failure.
 // body: "ms_m64_body" (needs M == 64, 64 threads per frame) or "lms_body" (ceil(M/64)*64 threads per frame).
+// compile == false: answer from the process cache or the on-disk cache only (nullptr, err empty when neither has it).
 inline const Kernel *get(int device, const char *body, const std::vector<std::vector<std::pair<int, int>>> &rows, int nh,
-                         int M, std::string &err) {
+                         int M, std::string &err, bool compile = true) {
     static std::mutex mu;
-    static std::map<std::string, Kernel> cache;
+    static std::map<std::string, Kernel> &cache = *new std::map<std::string, Kernel>();   // never destroyed: a background compile may outlive main()
     const std::string code = code_struct(rows, nh, M);
     const bool eight_waves = std::string(body) == "asp_body" || std::string(body) == "bp_body";  // 8 waves per frame, 2 frames per CU
     const bool four_waves = std::string(body) == "sp_body";                                       // 4 waves per frame, 2 frames per CU
     const int threads = eight_waves ? 512 : four_waves ? 256 : std::string(body) == "ms_chunk_body" ? 64 : ((M + 63) / 64) * 64;
     const std::string key = std::to_string(device) + "|" + body + "|" + code;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(key);
-    if (it != cache.end()) return &it->second;
+    // the lock covers the process cache only: a compile takes seconds and must not hold up other contexts
+    auto lookup = [&]() -> const Kernel * {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        return it != cache.end() ? &it->second : nullptr;
+    };
+    auto publish = [&](const Kernel &k) -> const Kernel * {
+        std::lock_guard<std::mutex> lk(mu);
+        return &cache.emplace(key, k).first->second;   // a concurrent compile of the same instance: the first one stays
+    };
+    if (const Kernel *k = lookup()) return k;
 
-    Rtc *r = rtc(err);
-    if (!r) return nullptr;
     const std::string hdr_path = this_library_dir() + "/csrc/ldpc_spec.hpp";
     std::ifstream hf(hdr_path);
     if (!hf) { err = "cannot read " + hdr_path; return nullptr; }
@@ -155,13 +169,14 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
             std::vector<char> bin((std::istreambuf_iterator<char>(cf)), std::istreambuf_iterator<char>());
             Kernel k;
             if (!bin.empty() && hipSetDevice(device) == hipSuccess && hipModuleLoadData(&k.mod, bin.data()) == hipSuccess &&
-                hipModuleGetFunction(&k.fn, k.mod, "spec_jit") == hipSuccess) {
-                auto ins = cache.emplace(key, k);
-                return &ins.first->second;
-            }
+                hipModuleGetFunction(&k.fn, k.mod, "spec_jit") == hipSuccess)
+                return publish(k);
             (void)hipGetLastError();   // unreadable / stale file: compile again below and overwrite it
         }
     }
+    if (!compile) return nullptr;
+    Rtc *r = rtc(err);
+    if (!r) return nullptr;
     hiprtcProgram prog = nullptr;
     const char *hdr_src[] = {hdr.c_str()};
     const char *hdr_name[] = {"ldpc_spec.hpp"};
@@ -196,8 +211,70 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
             if (rename(tmp.c_str(), cache_file.c_str()) != 0) (void)remove(tmp.c_str());
         }
     }
-    auto ins = cache.emplace(key, k);
-    return &ins.first->second;
+    return publish(k);
 }
+
+// ---- background specialisation ------------------------------------------------------------------------------------------
+// A context whose decoder has another HIP tier (table-driven or shape-unlimited kernel) need not wait seconds for hiprtc: it
+// starts on that tier, a single worker thread compiles the instance, and the context moves over at its next launch after the
+// instance is ready (every tier gives identical bits).  A code search opens thousands of short-lived contexts: jobs whose context
+// was closed before their turn are dropped; at exit the process waits for the one compile in flight, not for the queue.
+struct Job {
+    int device = 0, nh = 0, M = 0;
+    std::string body;
+    std::vector<std::vector<std::pair<int, int>>> rows;
+    std::atomic<int> state{0};          // 0 queued / compiling, 1 ready, 2 failed or dropped
+    std::atomic<bool> cancelled{false};
+    const Kernel *kernel = nullptr;
+    std::string err;
+};
+
+class Worker {
+public:
+    static Worker &instance() {
+        static Worker *w = new Worker();   // never destroyed; stop() runs from atexit
+        return *w;
+    }
+    void submit(const std::shared_ptr<Job> &j) {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!started_) {
+            started_ = true;
+            th_ = std::thread([this] { run(); });
+            atexit([] { Worker::instance().stop(); });
+        }
+        q_.push_back(j);
+        cv_.notify_one();
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+            cv_.notify_one();
+        }
+        if (th_.joinable()) th_.join();
+    }
+
+private:
+    void run() {
+        for (;;) {
+            std::shared_ptr<Job> j;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                if (stop_) return;
+                j = q_.back();   // newest first: its context is the one most likely still open
+                q_.pop_back();
+            }
+            if (j->cancelled.load()) { j->state.store(2); continue; }
+            j->kernel = get(j->device, j->body.c_str(), j->rows, j->nh, j->M, j->err, true);
+            j->state.store(j->kernel ? 1 : 2, std::memory_order_release);
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::shared_ptr<Job>> q_;
+    std::thread th_;
+    bool started_ = false, stop_ = false;
+};
 
 }  // namespace ldpc_jit

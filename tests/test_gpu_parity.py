@@ -840,3 +840,56 @@ def test_hiprtc_code_objects_can_be_cached_on_disk(L, tmp_path, monkeypatch):
     assert out2[2:] == out1[2:] and "hiprtc" in out2[0]
     assert float(out2[1]) < 0.5 * float(out1[1]) or float(out2[1]) < 0.3      # no compilation the second time
     assert [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")] == files
+
+
+@pytest.mark.parametrize("dec_id,first_tier", [(MS_DEC, "ms_flood_m64_kernel"), (TASP_DEC, "tasp_global_kernel"), (LMS_DEC, "lms_layered_kernel")])
+def test_background_specialisation_changes_tier_in_flight(L, torch, tmp_path, monkeypatch, dec_id, first_tier):
+    """LDPC_HIP_JIT=async (what ldpc::bp_simulation_t selects): ldpc_hip_open of an unseen code does not wait for hiprtc -- the
+    context starts on its table-driven / shape-unlimited kernel and moves to the code-specialised instance once the background
+    compile has delivered it; both tiers return the oracle's bits, a second context gets the instance from the process cache."""
+    import time
+    monkeypatch.setenv("LDPC_HIP_JIT", "async")
+    monkeypatch.setenv("LDPC_HIP_CACHE_DIR", str(tmp_path))
+    H = relift(load_base_matrix(), 64).copy()
+    H[H > 0] = (H[H > 0] * 11 + 2 + dec_id) % 64          # a code no other test has compiled in this process
+    maxit = 15 if dec_id == TASP_DEC else 50
+    llr = awgn_llr(H, 64, 1.8, 31 + dec_id, 96)
+    d_ref, it_ref, _ = Oracle(H, 64).decode(dec_id, llr, maxit, 0)
+    x = torch.from_numpy(llr).cuda()
+    t0 = time.perf_counter()
+    with L.LdpcHip(dec_id, H, 64) as dec:
+        t_open = time.perf_counter() - t0
+        assert first_tier in dec.kernel_name, dec.kernel_name
+        hard, iters, _ = dec.decode(x, maxit)
+        assert first_tier in dec.last_launch() or "hiprtc" in dec.kernel_name
+        assert np.array_equal(iters.cpu().numpy(), it_ref) and np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
+        t1 = time.perf_counter()
+        while "hiprtc" not in dec.kernel_name and time.perf_counter() - t1 < 180:
+            time.sleep(0.2)
+        assert "hiprtc" in dec.kernel_name, dec.kernel_name
+        t_jit = time.perf_counter() - t1
+        hard, iters, _ = dec.decode(x, maxit)
+        assert "hiprtc" in dec.last_launch()
+        assert np.array_equal(iters.cpu().numpy(), it_ref) and np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
+    assert t_open < 1.0 or t_open < 0.5 * t_jit, (t_open, t_jit)     # opening did not include the compile
+    with L.LdpcHip(dec_id, H, 64) as dec:
+        assert "hiprtc" in dec.kernel_name                            # process cache
+
+
+def test_contexts_closed_before_their_compile_are_dropped(L, torch, tmp_path, monkeypatch):
+    """A code search opens and closes a context per candidate: queued background compiles of closed contexts are skipped."""
+    import time
+    monkeypatch.setenv("LDPC_HIP_JIT", "async")
+    monkeypatch.setenv("LDPC_HIP_CACHE_DIR", str(tmp_path))
+    base = relift(load_base_matrix(), 64)
+    t0 = time.perf_counter()
+    for k in range(12):
+        H = base.copy()
+        H[H > 0] = (H[H > 0] * 13 + 5 + k) % 64
+        with L.LdpcHip(MS_DEC, H, 64) as dec:
+            s = dec.simulate(2.0, 50, seed=k, first_frame=0, B=2048)
+            assert s["frames"] == 2048
+    assert time.perf_counter() - t0 < 30.0          # 12 synchronous hiprtc compiles would take longer than this by themselves
+    # at most the compiles that were already running when their context closed reach the cache directory
+    time.sleep(0.5)
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) <= 12

@@ -41,8 +41,27 @@ for key, c in cfgs.items():
     # wave-iterations = waves of one dispatch x iterations each runs at the worst-case point
     d["wave_iterations"] = (d.get("SQ_WAVES") or c["frames"] * waves_per_frame) * c["maxiter"]
     out["kernels"][key] = d
+# the exact-replay generator: all ldpc_mt:: kernels of one generation round of 2^27 samples, summed (two rounds were run)
+acc, n = collections.defaultdict(float), collections.Counter()
+per_kernel = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc2", "exact_replay_generator", "*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        if "ldpc_mt::" not in k:
+            continue
+        acc[row["Counter_Name"]] += float(row["Counter_Value"])
+        per_kernel[k.split("(")[0].replace("void ", "")][row["Counter_Name"]] += float(row["Counter_Value"])
+if acc:
+    rounds = 2
+    d = {k: v / rounds for k, v in acc.items()}
+    d["samples"] = 1 << 27
+    d["per_kernel"] = {k: {c: v / rounds for c, v in cs.items()} for k, cs in per_kernel.items()}
+    out["kernels"]["exact_replay_generator"] = d
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r02_pmc.json"), "w"), indent=1)
 for k, d in out["kernels"].items():
+    if k == "exact_replay_generator":
+        print(k, "HBM bytes/sample %.1f" % ((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024 / d["samples"]), "VALU insts/sample %.1f" % (d.get("SQ_INSTS_VALU", 0) * 64 / d["samples"]))
+        continue
     print(k, d["kernel"][:50], "VALU/wave-iter %.0f" % (d["SQ_INSTS_VALU"] / d["wave_iterations"]), "LDS/wave-iter %.0f" % (d["SQ_INSTS_LDS"] / d["wave_iterations"]),
           "HBM bytes/frame %.0f" % ((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024 / d["frames"]))

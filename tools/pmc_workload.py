@@ -14,6 +14,17 @@ import ldpc_lib_amd  # noqa: E402
 from ldpc_testlib import load_base_matrix, relift  # noqa: E402
 
 key = sys.argv[1]
+if key == "exact_replay_generator":   # two generation rounds of 2^27 samples of upstream's noise stream (csrc/ldpc_mt.hpp)
+    H = relift(load_base_matrix(), 64)
+    with ldpc_lib_amd.LdpcHip(bench.DEC_MS, H, 64) as dec:
+        k, p = bench.mt19937_seeded(1)
+        dec.mt_set_state(k, p)
+        buf = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            dec.mt_normal(1 << 27, out=buf)
+        torch.cuda.synchronize()
+        print(key, "samples per round", 1 << 27)
+    sys.exit(0)
 cfgs = {c["key"]: c for c in bench.EXTRA_CONFIGS}
 cfgs["cfg2_min_sum"] = dict(dec=bench.DEC_MS, M=64, frames=bench.FRAMES_PER_GPU, maxiter=50, modulation=0)
 c = cfgs[key]
