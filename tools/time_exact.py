@@ -99,6 +99,31 @@ def main():
         row["speedup"] = row["host"]["seconds"] / row["device"]["seconds"]
         short[name] = row
     out["whole_call_latency_best_of_3"] = short
+    # a code search: one bp_simulation call per candidate matrix the library has never seen (main_good_code_search.cpp:320), shipped
+    # scenario settings (TDMP sum-product, 15 iterations, stop at 50 errored frames); hiprtc inside ldpc_hip_open vs in the background
+    import tempfile
+    search = {}
+    base = relift(load_base_matrix(), 64)
+    for mode in ("async", "sync"):
+        os.environ["LDPC_HIP_JIT"] = mode
+        os.environ["LDPC_HIP_EXACT_NOISE"] = "device"
+        with tempfile.TemporaryDirectory() as td:
+            os.environ["LDPC_HIP_CACHE_DIR"] = td
+            per = []
+            for k in range(6):
+                Hk = base.copy()
+                Hk[Hk > 0] = (Hk[Hk > 0] * (17 if mode == "async" else 19) + 3 + k) % 64
+                Hk = np.ascontiguousarray(Hk, dtype=np.int32)
+                res = (C.c_double * 7)()
+                nxt = C.c_uint()
+                t = time.perf_counter()
+                rc = lib.ldpc_bp_simulation_exact_perm(16, 32, Hk.ctypes.data, 64, 15, 50, 10**8, 1.7, 1.0, TASP_DEC, 0, 0, 128, 1, 0, 1, 0,
+                                                       C.addressof(res), C.addressof(nxt))
+                assert rc == 0
+                per.append({"seconds": time.perf_counter() - t, "frames": int(res[5])})
+            search[mode] = {"candidates": per, "mean_seconds": float(np.mean([p["seconds"] for p in per]))}
+    del os.environ["LDPC_HIP_JIT"], os.environ["LDPC_HIP_CACHE_DIR"]
+    out["code_search_like_loop_tasp_m64"] = search
     print(json.dumps(out, indent=1))
 
 
