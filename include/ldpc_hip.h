@@ -219,6 +219,9 @@ int ldpc_hip_mt_set_state(ldpc_hip_ctx *ctx, const uint32_t state[624], int pos)
 int ldpc_hip_mt_get_state(ldpc_hip_ctx *ctx, uint32_t state[624], int *pos);
 /* The next `count` values of next_random_gaussian() (commons_portable.cpp:174-178) to d_out [count] (device; NULL = draw and drop). */
 int ldpc_hip_mt_normal_dev(ldpc_hip_ctx *ctx, long long count, double *d_out, void *stream);
+/* Same into a HOST array (convenience; the harness uses it to check once per process that the device stream reproduces THIS host's
+ * std::normal_distribution before relying on it). */
+int ldpc_hip_mt_normal_host(ldpc_hip_ctx *ctx, long long count, double *out);
 /* Decoder input of the next B frames exactly as the frame loop builds it: y = -2*(sigma*g + 2*c - 1)/sigma^2 with g drawn in index
  * order (bp_simulation.cpp:600-611, sigma :445 / :449; c = 0 unless ldpc_hip_set_codewords), inverse interleaver (:684,
  * ldpc_hip_set_interleaver), puncturing (:697-710).  modulation_type 0 or 1.  d_llr [B][N] device, NULL = draw and drop (used to put

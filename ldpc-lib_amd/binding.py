@@ -120,6 +120,7 @@ def load_library():
     lib.ldpc_hip_mt_set_state.argtypes = [vp, vp, i32]
     lib.ldpc_hip_mt_get_state.argtypes = [vp, vp, C.POINTER(i32)]
     lib.ldpc_hip_mt_normal_dev.argtypes = [vp, i64, vp, vp]
+    lib.ldpc_hip_mt_normal_host.argtypes = [vp, i64, vp]
     lib.ldpc_hip_mt_llr_dev.argtypes = [vp, f64, i32, i32, i64, vp, vp]
     lib.ldpc_hip_mt_frames.argtypes = [vp, f64, i32, i32, i32, f64, i64, vp, vp]
     if lib.ldpc_hip_abi_version() != 3:

@@ -207,6 +207,19 @@ int ldpc_hip_mt_normal_dev(ldpc_hip_ctx *c, long long count, double *d_out, void
     return 0;
 }
 
+int ldpc_hip_mt_normal_host(ldpc_hip_ctx *c, long long count, double *out) {
+    if (!c || count < 0 || (count > 0 && !out)) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_normal_host: bad argument");
+    if (count == 0) return 0;
+    if (int rc = set_device(c)) return rc;
+    double *d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(double) * (size_t)count));
+    int rc = ldpc_hip_mt_normal_dev(c, count, d, nullptr);
+    if (rc == 0 && hipMemcpy(out, d, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(LDPC_HIP_EHIP, "ldpc_hip_mt_normal_host: copy back failed");
+    (void)hipFree(d);
+    return rc;
+}
+
 int ldpc_hip_mt_llr_dev(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, long long B, double *d_llr, void *stream_) {
     if (!c || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_llr_dev: bad argument");
     if (int rc = set_device(c)) return rc;

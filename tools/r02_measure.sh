@@ -21,3 +21,16 @@ PY
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02/trace -- python3 bench.py --no-cpu-baseline > gpurun_out/r02/r02_bench_under_rocprof.json 2> gpurun_out/r02/trace.err || { tail -5 gpurun_out/r02/trace.err; exit 1; }
 find gpurun_out/r02/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r02/r02_kernel_stats.csv
 head -12 gpurun_out/r02/r02_kernel_stats.csv | cut -c1-160
+# the exact-replay path: generator, noise -> decode -> count, harness end to end, whole-call latency, code-search-like loop
+timeout -k 10 500 python tools/time_exact.py > gpurun_out/r02/r02_exact_replay.json 2> gpurun_out/r02/time_exact.err || { tail -5 gpurun_out/r02/time_exact.err; exit 1; }
+python3 - <<'PY'
+import json
+d=json.load(open("gpurun_out/r02/r02_exact_replay.json"))
+for k in ("generator","mt_frames_B65536","decode_only_B65536","harness_device_noise","harness_host_noise"): print(k, {a:(round(b,4) if isinstance(b,float) else b) for a,b in d[k].items()})
+for k,v in d["whole_call_latency_best_of_3"].items(): print(k, round(v["device"]["seconds"]*1e3,2), "ms device", round(v["host"]["seconds"]*1e3,2), "ms host")
+for k,v in d["code_search_like_loop_tasp_m64"].items(): print("search loop", k, "mean s/candidate", round(v["mean_seconds"],3), [round(p["seconds"],3) for p in v["candidates"]])
+PY
+rm -rf gpurun_out/r02/trace_exact
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02/trace_exact -- python3 tools/time_exact.py --frames 100000 --host-frames 100 > /dev/null 2> gpurun_out/r02/trace_exact.err || { tail -5 gpurun_out/r02/trace_exact.err; exit 1; }
+find gpurun_out/r02/trace_exact -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r02/r02_exact_replay_kernel_stats.csv
+head -9 gpurun_out/r02/r02_exact_replay_kernel_stats.csv | cut -c1-150
