@@ -10,8 +10,8 @@
 //       [Haramoto, Matsumoto, Nishimura, Panneton, L'Ecuyer 2008].  With x^J = g_J mod phi every word of the sequence obeys
 //       x[t+J] = XOR over the set bits i of g_J of x[t+i] -- a GF(2) convolution over 19937 + 624 consecutive words
 //       (mt_jump_kernel: the words in LDS, up to 8 workgroups per jump, each taking a share of g_J's ~10^4 set coefficients).  The host computes phi (Berlekamp-Massey on an output bit
-//       sequence) and g_J for J = 2^20 .. 2^29 by repeated squaring once per process (~60 ms) and checks the first against a plain
-//       2^20-step walk.  S stream states are reached in ceil(log2 S) doubling rounds; then one WAVEFRONT per stream runs the
+//       sequence) and g_J for J = 2^18 .. 2^29 by repeated squaring once per process (~60 ms) and checks the first against a plain
+//       2^18-step walk.  S stream states are reached in ceil(log2 S) doubling rounds; then one WAVEFRONT per stream runs the
 //       recurrence in place over its 624-word block in LDS, 192 words per step with every LDS address an immediate offset
 //       (mt_generate_kernel), writing the untempered words to HBM.
 //   libstdc++'s normal_distribution (bits/random.tcc: Marsaglia polar method): an attempt takes four 32-bit words (two
@@ -35,10 +35,11 @@
 namespace ldpc_mt {
 
 constexpr int MTN = 624;
-constexpr int kLog2Stride = 20;                       // words per stream
+constexpr int kLog2Stride = 18;                       // shortest stream: 2^18 words (a round picks 2^18, 2^19 or 2^20 by its size)
+constexpr int kLog2StrideMax = 20;
 constexpr long long kStride = 1ll << kLog2Stride;
-constexpr int kLevels = 10;                           // jump polynomials for 2^20 .. 2^29 words: up to 1024 streams per round
-constexpr int kMaxStreams = 1 << kLevels;
+constexpr int kLevels = 12;                           // jump polynomials for 2^18 .. 2^29 words
+constexpr int kMaxStreams = 1024;                     // streams per round
 constexpr int kDegree = 19937;
 constexpr int kMaxBits = 10752;                        // set coefficients per polynomial: 19937 / 2 +- a few hundred
 constexpr int kSeqWords = 20608;                      // >= 19937 + 624 + 31: the LDS image of one jump (82 432 bytes)
@@ -58,7 +59,7 @@ __host__ __device__ inline uint32_t mt_temper(uint32_t y) {
 
 // ---- host: the jump polynomials -------------------------------------------------------------------------------------------
 struct JumpPolys {
-    std::vector<uint32_t> poly;   // [kLevels][624]: bit i of level e = coefficient of x^i in x^(2^(20+e)) mod phi
+    std::vector<uint32_t> poly;   // [kLevels][624]: bit i of level e = coefficient of x^i in x^(2^(18+e)) mod phi
     std::vector<uint32_t> bits;   // [kLevels][kMaxBits]: the exponents i with a set coefficient, ascending (what the device walks)
     std::vector<int> nbits;       // [kLevels]
     bool ok = false;
@@ -251,8 +252,9 @@ __global__ void __launch_bounds__(640) mt_jump_kernel(const JumpArgs a) {
 // ---- device: one wavefront per stream ---------------------------------------------------------------------------------------
 struct GenArgs {
     const uint32_t *states;   // [S][624]
-    uint32_t *xraw;           // [624 + S * kStride] untempered words; stream j writes [624 + j*kStride, 624 + (j+1)*kStride)
+    uint32_t *xraw;           // [624 + S * stride] untempered words; stream j writes [624 + j*stride, 624 + (j+1)*stride)
     int S;
+    int log2_stride;          // 18 .. 20
     long long words;          // words wanted behind the first 624 (a multiple of 64): the last stream stops there
 };
 
@@ -303,10 +305,12 @@ __global__ void __launch_bounds__(256) mt_generate_kernel(const GenArgs a) {
         if (j == 0) a.xraw[i] = v;
     }
     mt_wave_sync();
-    uint32_t *out = a.xraw + (size_t)j * kStride + MTN;   // the stream's words [0, kStride)
-    static_assert((kStride % MTN) % 64 == 0, "the last block of a stream must end on a sub-step boundary");
-    const long long left = a.words - (long long)j * kStride;
-    const uint32_t nwords = left >= kStride ? (uint32_t)kStride : left > 0 ? (uint32_t)left : 0u;   // a short round stops early
+    const long long stride = 1ll << a.log2_stride;
+    uint32_t *out = a.xraw + (size_t)j * (size_t)stride + MTN;   // the stream's words [0, stride)
+    static_assert(((1ll << 18) % MTN) % 64 == 0 && ((1ll << 19) % MTN) % 64 == 0 && ((1ll << 20) % MTN) % 64 == 0,
+                  "the last block of a stream must end on a sub-step boundary");
+    const long long left = a.words - (long long)j * stride;
+    const uint32_t nwords = left >= stride ? (uint32_t)stride : left > 0 ? (uint32_t)left : 0u;   // a short round stops early
     for (uint32_t w0 = 0; w0 < nwords; w0 += MTN) {   // the classic in-place block update, 3 + 3 + 3 + 1 sub-steps
         const uint32_t remaining = nwords - w0;
         uint32_t *ob = out + w0;
@@ -423,9 +427,11 @@ __global__ void __launch_bounds__(256) mt_polar_kernel(const PolarArgs a) {
 }
 
 // exclusive scan of the per-block counts (one workgroup; nb is a few 10^4)
-__global__ void __launch_bounds__(1024) mt_scan_kernel(const uint32_t *cnt, unsigned long long *base, unsigned long long *total, long long nb) {
+__global__ void __launch_bounds__(1024) mt_scan_kernel(const uint32_t *cnt, unsigned long long *base, unsigned long long *total, long long nb,
+                                                       long long *end_t, long long end_preset) {
     __shared__ unsigned long long part[1024];
     const int tid = threadIdx.x;
+    if (tid == 0) *end_t = end_preset;   // where the generator stays if the emit pass emits nothing
     const long long per = (nb + 1023) / 1024, lo = per * tid, hi = lo + per < nb ? lo + per : nb;
     unsigned long long s = 0;
     for (long long i = lo; i < hi; ++i) s += cnt[i];
@@ -451,7 +457,6 @@ __global__ void __launch_bounds__(640) mt_adopt_kernel(const uint32_t *xraw, con
 struct DeviceState {
     bool set = false;
     int pos = 0;                         // next word of d_state to draw (0..624); 0 after every generation round
-    long long h_end = 0;                 // staging for the end-offset preset
     uint32_t *d_state = nullptr;         // [624]
     uint32_t *d_bits = nullptr;          // [kLevels][kMaxBits] exponents of the jump polynomials
     uint32_t *d_states = nullptr;        // [cap_streams][624]

@@ -27,10 +27,15 @@ int mt_round(ldpc_hip_ctx *c, unsigned long long need, ldpc_mt::PolarArgs proto,
     const double g = (double)need;
     // attempts for `need` accepted ones at p = pi/4, plus ~8 standard deviations (negative binomial: sd = 0.59 sqrt(need))
     const long long A = (long long)(g * 1.2732395447351628 + 5.0 * std::sqrt(g) + 64.0);
-    long long S = (m.pos + 4 * A + kStride - 1) / kStride;
+    // stream length by the size of the round: the generate kernel is bound by the latency of one wave walking its stream, the
+    // jumps by their number -- short streams for small rounds, 2^20 words for the 65536-frame batches
+    const long long want = m.pos + 4 * A;
+    const int ls = want <= (1ll << 26) ? 18 : want <= (1ll << 28) ? 19 : kLog2StrideMax;
+    const long long stride = 1ll << ls;
+    long long S = (want + stride - 1) / stride;
     if (S < 1) S = 1;
     if (S > kMaxStreams) S = kMaxStreams;
-    const size_t words = (size_t)MTN + (size_t)S * (size_t)kStride;
+    const size_t words = (size_t)MTN + (size_t)S * (size_t)stride;
     if (S > m.cap_streams) {
         if (m.d_states) (void)hipFree(m.d_states);
         m.d_states = nullptr; m.cap_streams = 0;
@@ -43,10 +48,10 @@ int mt_round(ldpc_hip_ctx *c, unsigned long long need, ldpc_mt::PolarArgs proto,
         HIP_TRY(hipMalloc(&m.d_xraw, sizeof(uint32_t) * words));
         m.cap_words = words;
     }
-    long long attempts = ((long long)S * kStride - m.pos) / 4;   // the last 624 words stay unread: they are the next state
+    long long attempts = (S * stride - m.pos) / 4;   // the last 624 words stay unread: they are the next state
     if (attempts > A) attempts = A;                              // a short round neither generates nor scans a whole stream
     long long gen_words = (m.pos + 4 * attempts + 63) / 64 * 64;  // words behind the first 624 that the round reads or adopts
-    if (gen_words > (long long)S * kStride) gen_words = (long long)S * kStride;
+    if (gen_words > S * stride) gen_words = S * stride;
     const long long nb = (attempts + 256 * kPolarSub - 1) / (256 * kPolarSub);
     if (nb > m.cap_blocks) {
         if (m.d_blockcnt) (void)hipFree(m.d_blockcnt);
@@ -62,17 +67,16 @@ int mt_round(ldpc_hip_ctx *c, unsigned long long need, ldpc_mt::PolarArgs proto,
     for (int level = 0; (1ll << level) < S; ++level) {   // stream j + 2^level from stream j, j < 2^level
         const long long have = 1ll << level, cnt = have < S - have ? have : S - have;
         const int parts = cnt >= 256 ? 1 : cnt >= 128 ? 2 : cnt >= 64 ? 4 : 8;   // few jumps: spread each over several CUs
-        JumpArgs ja{m.d_states, m.d_bits + (size_t)level * kMaxBits, J.nbits[(size_t)level], parts, 0, (int)have};
+        const size_t pl = (size_t)(ls - kLog2Stride + level);   // the polynomial of 2^(ls + level) words
+        JumpArgs ja{m.d_states, m.d_bits + pl * kMaxBits, J.nbits[pl], parts, 0, (int)have};
         hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(cnt * parts)), dim3(640), sizeof(uint32_t) * kSeqWords, st, ja);
     }
-    GenArgs ga{m.d_states, m.d_xraw, (int)S, gen_words};
+    GenArgs ga{m.d_states, m.d_xraw, (int)S, ls, gen_words};
     hipLaunchKernelGGL(mt_generate_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, ga);
     proto.xraw = m.d_xraw; proto.p = m.pos; proto.attempts = attempts;
     proto.blockcnt = m.d_blockcnt; proto.blockbase = m.d_blockbase; proto.total = m.d_total; proto.need = need; proto.end_t = m.d_end_t;
     hipLaunchKernelGGL(mt_polar_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, proto);
-    hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(1024), 0, st, m.d_blockcnt, m.d_blockbase, m.d_total, nb);
-    m.h_end = m.pos;
-    HIP_TRY(hipMemcpyAsync(m.d_end_t, &m.h_end, sizeof(long long), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(1024), 0, st, m.d_blockcnt, m.d_blockbase, m.d_total, nb, m.d_end_t, (long long)m.pos);
     hipLaunchKernelGGL(mt_polar_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, proto);
     hipLaunchKernelGGL(mt_adopt_kernel, dim3(1), dim3(640), 0, st, m.d_xraw, m.d_end_t, m.d_state);
     HIP_TRY(hipGetLastError());

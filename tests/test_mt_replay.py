@@ -46,7 +46,7 @@ def L():
     return ldpc_lib_amd
 
 
-@pytest.mark.parametrize("log2_words", [20, 21, 24, 26])
+@pytest.mark.parametrize("log2_words", [18, 19, 20, 21, 24, 26])
 def test_jump_polynomial_equals_a_plain_walk(L, log2_words):
     """state after 2^k words by x^(2^k) mod phi == the recurrence walked 2^k words (numpy's MT19937)."""
     from ldpc_lib_amd.binding import mt_jump_host
