@@ -231,6 +231,10 @@ int ldpc_hip_mt_llr_dev(ldpc_hip_ctx *ctx, double snr_db, int modulation_type, i
  * Synchronous.  The stopping rule (bp_simulation.cpp:591,820) is the caller's, on the ordered records. */
 int ldpc_hip_mt_frames(ldpc_hip_ctx *ctx, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha, long long B,
                        int32_t *frame_info, int32_t *iters);
+/* One rank's share when every rank (process or shard) runs the same generator: the stream advances by all B frames, frames
+ * [lo, hi) are decoded and counted here; frame_info / iters have hi - lo entries. */
+int ldpc_hip_mt_frames_slice(ldpc_hip_ctx *ctx, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha, long long B,
+                             long long lo, long long hi, int32_t *frame_info, int32_t *iters);
 
 /* ---- several GPUs of one node (bp_simulation's frame loop sharded; north_star: RCCL all-reduce for the counters only) ----
  * One shard = one context + one HIP stream + one host thread.  devices[i] is the HIP ordinal of shard i; ordinals may repeat

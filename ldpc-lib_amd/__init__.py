@@ -11,7 +11,7 @@ There is deliberately no CPU fallback: importing works anywhere, but every compu
 """
 from .binding import (DEC_ASP, DEC_BP, DEC_IMS, DEC_LMS, DEC_MS, DEC_SP, DEC_TASP, LdpcHip, LdpcHipError, LdpcHipMulti, build_library, library_path,  # noqa: F401
                       load_library)
-from .host import GpuFrameSource, bp_simulation, relift_base_matrix, replay_stopping_rule  # noqa: F401
+from .host import GpuFrameSource, MtFrameSource, bp_simulation, mt19937_state, relift_base_matrix, replay_stopping_rule  # noqa: F401
 
 __all__ = ["LdpcHip", "LdpcHipError", "DEC_BP", "DEC_SP", "DEC_ASP", "DEC_MS", "DEC_IMS", "DEC_TASP", "DEC_LMS", "build_library", "library_path",
            "load_library", "bp_simulation", "relift_base_matrix"]

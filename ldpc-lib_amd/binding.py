@@ -123,6 +123,7 @@ def load_library():
     lib.ldpc_hip_mt_normal_host.argtypes = [vp, i64, vp]
     lib.ldpc_hip_mt_llr_dev.argtypes = [vp, f64, i32, i32, i64, vp, vp]
     lib.ldpc_hip_mt_frames.argtypes = [vp, f64, i32, i32, i32, f64, i64, vp, vp]
+    lib.ldpc_hip_mt_frames_slice.argtypes = [vp, f64, i32, i32, i32, f64, i64, i64, i64, vp, vp]
     if lib.ldpc_hip_abi_version() != 3:
         raise LdpcHipError("libldpc_hip.so ABI version mismatch")
     _lib = lib
@@ -295,13 +296,16 @@ class LdpcHip:
         _check(self.lib, rc, "ldpc_hip_mt_llr_dev")
         return out
 
-    def mt_frames(self, snr_db, maxiter, B, modulation=0, punctured_blocks=0, alpha=0.8):
-        """noise -> decode -> count for the next B frames: (frame_info[B], iters[B]) int32 numpy arrays."""
-        info = np.empty(int(B), dtype=np.int32)
-        its = np.empty(int(B), dtype=np.int32)
-        rc = self.lib.ldpc_hip_mt_frames(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(maxiter), float(alpha), int(B),
-                                         info.ctypes.data, its.ctypes.data)
-        _check(self.lib, rc, "ldpc_hip_mt_frames")
+    def mt_frames(self, snr_db, maxiter, B, modulation=0, punctured_blocks=0, alpha=0.8, lo=None, hi=None):
+        """noise -> decode -> count for the next B frames: (frame_info, iters) int32 numpy arrays.  With lo / hi the generator still
+        advances by all B frames but only frames [lo, hi) are decoded here (one rank's share when every rank runs the generator)."""
+        lo = 0 if lo is None else int(lo)
+        hi = int(B) if hi is None else int(hi)
+        info = np.empty(max(hi - lo, 0), dtype=np.int32)
+        its = np.empty(max(hi - lo, 0), dtype=np.int32)
+        rc = self.lib.ldpc_hip_mt_frames_slice(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(maxiter), float(alpha), int(B),
+                                               lo, hi, info.ctypes.data, its.ctypes.data)
+        _check(self.lib, rc, "ldpc_hip_mt_frames_slice")
         return info, its
 
     # ---- host-pointer API (upstream array layout, PCIe inclusive) --------------------------------------

@@ -230,6 +230,13 @@ int ldpc_hip_mt_llr_dev(ldpc_hip_ctx *c, double snr_db, int modulation_type, int
     return mt_llr_rows(c, snr_db, modulation_type, punctured_blocks, B, 0, B, d_llr, (hipStream_t)stream_);
 }
 
+int ldpc_hip_mt_frames_slice(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha, long long B,
+                             long long lo, long long hi, int32_t *frame_info, int32_t *iters) {
+    if (!c || B < 0 || lo < 0 || hi < lo || hi > B || (hi > lo && (!frame_info || !iters))) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_frames_slice: bad argument");
+    if (int rc = set_device(c)) return rc;
+    return mt_frames_slice(c, snr_db, modulation_type, punctured_blocks, maxiter, alpha, B, lo, hi, frame_info, iters, nullptr);
+}
+
 int ldpc_hip_mt_frames(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha, long long B,
                        int32_t *frame_info, int32_t *iters) {
     if (!c || B < 0 || !frame_info || !iters) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_frames: bad argument");

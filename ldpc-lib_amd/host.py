@@ -6,8 +6,10 @@ the global frame index), decodes frames in batches and -- because the upstream s
 order (bp_simulation.cpp:591,820) -- replays that rule over the ordered per-frame records of each batch, so the result
 is exactly what a frame-by-frame loop over the same noise would return, whatever the batch size or GPU count.
 
-The bit-exact drop-in for upstream's C++ callers (same mt19937 noise as upstream) is the C++ layer in
-csrc/compat/; this module is its throughput-mode sibling.
+`exact_seed=` switches to EXACT REPLAY: the noise is upstream's own stream -- std::mt19937(seed) through a fresh
+std::normal_distribution per sample, after the codeword draws of bp_simulation.cpp:512 -- continued on the GPU (csrc/ldpc_mt.hpp), so
+counters, BER / FER and the generator state afterwards are upstream's, bit for bit.  With several ranks every rank runs the same
+generator over the whole round and decodes its slice.  The C++ layer in csrc/compat/ does the same for upstream's C++ callers.
 """
 import numpy as np
 
@@ -84,9 +86,59 @@ class GpuFrameSource:
         self.dec.close()
 
 
+def mt19937_state(seed, skip_words=0):
+    """(624 words, next index) of std::mt19937(seed) after `skip_words` raw draws: init_genrand, then the public recurrence
+    (numpy's MT19937 bit generator walks it)."""
+    key = np.empty(624, dtype=np.uint64)
+    key[0] = int(seed) & 0xffffffff
+    for i in range(1, 624):
+        key[i] = (1812433253 * (int(key[i - 1]) ^ (int(key[i - 1]) >> 30)) + i) & 0xffffffff
+    bg = np.random.MT19937()
+    st = bg.state
+    st["state"]["key"] = key.astype(np.uint32)
+    st["state"]["pos"] = 624
+    bg.state = st
+    if skip_words:
+        bg.random_raw(int(skip_words))
+    return bg.state["state"]["key"].astype(np.uint32), int(bg.state["state"]["pos"])
+
+
+class MtFrameSource:
+    """Exact replay: round(total, lo, hi) -> records of frames [lo, hi) of the next `total` frames of upstream's own noise stream
+    (ldpc_hip_mt_frames_slice).  Every rank holds the same generator and advances it by `total`."""
+
+    def __init__(self, H, tailbite_length, decoder_type, max_iterations, snr, modulation_type, punctured_blocks, seed, device, alpha):
+        H = np.asarray(H)
+        self.dec = LdpcHip(decoder_type, H, tailbite_length, device)
+        self.n, self.r = self.dec.N, self.dec.R
+        self.args = (snr, modulation_type, punctured_blocks, max_iterations, alpha)
+        # random_codeword() draws (nh - rh) * M values of next_random_int(0, 2) first, one generator word each (bp_simulation.cpp:512,160-162)
+        self.dec.mt_set_state(*mt19937_state(seed, (H.shape[1] - H.shape[0]) * tailbite_length))
+
+    def snapshot(self):
+        return self.dec.mt_get_state()
+
+    def restore_and_skip(self, snap, frames):
+        """the generator where a frame-by-frame loop that stopped after `frames` frames of the round would have left it"""
+        snr, mod, punct, _, _ = self.args
+        self.dec.mt_set_state(*snap)
+        if frames:
+            self.dec.mt_llr(snr, frames, modulation=mod, punctured_blocks=punct, skip=True)
+
+    def round(self, total, lo, hi):
+        import torch
+        snr, mod, punct, maxit, alpha = self.args
+        info, its = self.dec.mt_frames(snr, maxit, total, modulation=mod, punctured_blocks=punct, alpha=alpha, lo=lo, hi=hi)
+        dev = torch.device("cuda", self.dec.device)   # device tensors: the record exchange may run over RCCL
+        return torch.from_numpy(info).to(dev), torch.from_numpy(its).to(dev)
+
+    def close(self):
+        self.dec.close()
+
+
 def bp_simulation(H, tailbite_length, max_iterations, n_frame_errors, n_experiments, snr, reference_frame_error,
                   decoder_type=DEC_MS, modulation_type=MODULATION_SKIP, punctured_blocks=0, seed=1, device=0,
-                  batch=16384, alpha=0.8, return_state=False, source=None, group=None):
+                  batch=16384, alpha=0.8, return_state=False, source=None, group=None, exact_seed=None):
     """Returns (BER, FER) = (nse/experiment/(n-r), nde/experiment) like bp_simulation.cpp:840.
 
     Multi-GPU (torch.distributed initialised, one process per GPU): every round covers world*batch consecutive global
@@ -99,8 +151,12 @@ def bp_simulation(H, tailbite_length, max_iterations, n_frame_errors, n_experime
     world, rank = 1, 0
     if dist.is_available() and dist.is_initialized():
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-    src = source if source is not None else GpuFrameSource(H, tailbite_length, decoder_type, max_iterations, snr,
-                                                           modulation_type, punctured_blocks, seed, device, alpha)
+    if source is None and exact_seed is not None:
+        src = MtFrameSource(H, tailbite_length, decoder_type, max_iterations, snr, modulation_type, punctured_blocks, exact_seed, device, alpha)
+    else:
+        src = source if source is not None else GpuFrameSource(H, tailbite_length, decoder_type, max_iterations, snr,
+                                                               modulation_type, punctured_blocks, seed, device, alpha)
+    exact = isinstance(src, MtFrameSource)
     n, r = src.n, src.r
     state = {"nse": 0, "nde": 0, "nue": 0, "experiment": 0, "sum_abs_iters": 0}
     base, stop = 0, False
@@ -108,7 +164,11 @@ def bp_simulation(H, tailbite_length, max_iterations, n_frame_errors, n_experime
         while not stop:
             room = max(1, n_experiments + 1 - state["experiment"])
             B = int(min(batch, -(-room // world)))           # frames per rank this round
-            info, iters = src.frames(base + rank * B, B)
+            if exact:
+                snap = src.snapshot()
+                info, iters = src.round(world * B, rank * B, (rank + 1) * B)
+            else:
+                info, iters = src.frames(base + rank * B, B)
             rec = torch.stack([info.to(torch.int32), iters.to(torch.int32)])  # [2, B]
             if world > 1:
                 gathered = [torch.empty_like(rec) for _ in range(world)]
@@ -119,7 +179,11 @@ def bp_simulation(H, tailbite_length, max_iterations, n_frame_errors, n_experime
             stop = replay_stopping_rule(rec_h[0], rec_h[1], state, n_frame_errors, n_experiments, reference_frame_error)
             used = state["experiment"] - before
             state["sum_abs_iters"] += int(np.abs(rec_h[1][:used]).sum())
+            if exact and used < world * B:
+                src.restore_and_skip(snap, used)      # stopped inside the round
             base += world * B
+        if exact:
+            state["generator"] = src.snapshot()       # (624 words, next index): what upstream's `generator` holds afterwards
     finally:
         if source is None:
             src.close()

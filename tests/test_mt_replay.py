@@ -303,3 +303,72 @@ def test_generator_needs_a_state_and_sane_arguments(L, torch):
         assert dec.mt_normal(0).numel() == 0
         info, its = dec.mt_frames(2.0, 50, 0)
         assert info.shape == (0,) and its.shape == (0,)
+
+
+# ---- the Python harness (ldpc_lib_amd.bp_simulation(exact_seed=...)), one process and two ranks ----------------------------------
+_EXACT_CASES = [(MS_DEC, 64, 2.0, 50, 10**9, 4000, 1.0, 1), (MS_DEC, 64, 1.2, 50, 10**9, 5000, 0.02, 1), (LMS_DEC, 64, 1.5, 50, 12, 10**6, 1.0, 7)]
+
+
+def _oracle_sim(H, M, dec_id, snr, maxit, n_fe, n_exp, ref, seed):
+    from ldpc_testlib import SimResult, c_int_p
+    Hc = np.ascontiguousarray(H, dtype=np.int32)
+    res = SimResult()
+    assert oracle_lib().orc_bp_simulation(16, 32, Hc.ctypes.data_as(c_int_p), M, maxit, n_fe, n_exp, snr, ref, dec_id, 0, 0, seed, C.byref(res), None) == 0
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dec_id,M,snr,maxit,n_fe,n_exp,ref,seed", _EXACT_CASES)
+def test_python_harness_exact_replay(L, torch, dec_id, M, snr, maxit, n_fe, n_exp, ref, seed):
+    H = relift(load_base_matrix(), M)
+    ber, fer, st = L.bp_simulation(H, M, maxit, n_fe, n_exp, snr, ref, decoder_type=dec_id, exact_seed=seed, batch=3000, return_state=True)
+    res = _oracle_sim(H, M, dec_id, snr, maxit, n_fe, n_exp, ref, seed)
+    assert (st["nse"], st["nde"], st["nue"], st["experiment"], st["sum_abs_iters"]) == (res.nse, res.nde, res.nue, res.experiment, res.sum_abs_iter)
+    assert ber == res.ber and fer == res.fer
+    assert int(raw_after(*st["generator"], 0, 1)[0]) == res.rng_next
+
+
+_EXACT_RANK_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import ldpc_lib_amd
+from ldpc_testlib import load_base_matrix, relift
+from test_mt_replay import _EXACT_CASES, raw_after
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+out = []
+for dec_id, M, snr, maxit, n_fe, n_exp, ref, seed in _EXACT_CASES:
+    H = relift(load_base_matrix(), M)
+    ber, fer, st = ldpc_lib_amd.bp_simulation(H, M, maxit, n_fe, n_exp, snr, ref, decoder_type=dec_id, exact_seed=seed, batch=700, return_state=True)
+    out.append([st["nse"], st["nde"], st["nue"], st["experiment"], st["sum_abs_iters"], ber.hex(), fer.hex(), int(raw_after(*st["generator"], 0, 1)[0])])
+print("RESULT", dist.get_rank(), json.dumps(out))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_two_ranks_exact_replay(L, torch):
+    """one process per GPU (here: two processes on the one GPU, gloo for the records): every rank runs the same generator over the
+    whole round and decodes its slice -- both must report the sequential loop's counters, doubles and generator state."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = []
+    for dec_id, M, snr, maxit, n_fe, n_exp, ref, seed in _EXACT_CASES:
+        res = _oracle_sim(relift(load_base_matrix(), M), M, dec_id, snr, maxit, n_fe, n_exp, ref, seed)
+        want.append([res.nse, res.nde, res.nue, res.experiment, res.sum_abs_iter, float(res.ber).hex(), float(res.fer).hex(), res.rng_next])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _EXACT_RANK_WORKER.format(root=root)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for o in outs:
+        line = [ln for ln in o.splitlines() if ln.startswith("RESULT")][0]
+        assert json.loads(line.split(" ", 2)[2]) == want
