@@ -153,6 +153,80 @@ def test_two_rank_gloo_run_matches_single_process():
         assert json.loads(line.split(" ", 2)[2]) == want
 
 
+def _fake_mt_source():
+    """The exact-replay source without a GPU: the `generator` is a frame counter (a sequential stream every rank must advance
+    identically, snapshot / restore-and-skip included), the records are FakeSource's function of the stream position."""
+    import ldpc_lib_amd
+
+    class FakeMtSource(ldpc_lib_amd.MtFrameSource):
+        n, r = 2048, 1024
+
+        def __init__(self):
+            self.pos = 0
+
+        def snapshot(self):
+            return self.pos
+
+        def restore_and_skip(self, snap, frames):
+            self.pos = snap + frames
+
+        def round(self, total, lo, hi):
+            info, iters = FakeSource().frames(self.pos + lo, hi - lo)
+            self.pos += total
+            return info, iters
+
+        def close(self):
+            pass
+
+    return FakeMtSource()
+
+
+@pytest.mark.parametrize("n_fe,n_exp,ref,batch", [(10**9, 999, 1.0, 64), (25, 10**6, 1.0, 100), (10**9, 5000, 0.001, 257), (3, 50, 1.0, 1000)])
+def test_exact_replay_branch_of_the_host_harness(n_fe, n_exp, ref, batch):
+    """sequential-generator bookkeeping: same counters as the frame-by-frame loop, and the generator ends exactly `experiment`
+    frames on, also when the run stops inside a round"""
+    import ldpc_lib_amd
+    _, _, st = ldpc_lib_amd.bp_simulation(None, 64, 50, n_fe, n_exp, 2.0, ref, batch=batch, source=_fake_mt_source(), return_state=True)
+    assert (st["nse"], st["nde"], st["nue"], st["experiment"]) == _brute(n_fe, n_exp, ref)
+    assert st["generator"] == st["experiment"]
+
+
+_EXACT_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch.distributed as dist
+import ldpc_lib_amd
+from test_host_cpu import _fake_mt_source
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+out = []
+for n_fe, n_exp, ref, batch in [(10**9, 999, 1.0, 64), (25, 10**6, 1.0, 100), (10**9, 5000, 0.001, 257), (3, 50, 1.0, 1000)]:
+    _, _, st = ldpc_lib_amd.bp_simulation(None, 64, 50, n_fe, n_exp, 2.0, ref, batch=batch, source=_fake_mt_source(), return_state=True)
+    out.append([st["nse"], st["nde"], st["nue"], st["experiment"], st["generator"]])
+print("RESULT", dist.get_rank(), json.dumps(out))
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_exact_replay_matches_single_process():
+    """N > 1 exact replay on CPU: every rank advances the same sequential generator by the whole round and takes its slice."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", _EXACT_WORKER.format(root=ROOT)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    import json
+    want = [list(_brute(*c[:3])) for c in [(10**9, 999, 1.0), (25, 10**6, 1.0), (10**9, 5000, 0.001), (3, 50, 1.0)]]
+    want = [w + [w[3]] for w in want]
+    for o in outs:
+        line = [ln for ln in o.splitlines() if ln.startswith("RESULT")][0]
+        assert json.loads(line.split(" ", 2)[2]) == want
+
+
 def test_c_example_builds_against_the_header(tmp_path):
     """examples/simulate.c and simulate_multi.c are plain C: the header must be C-clean and the library must link from gcc."""
     for name in ("simulate", "simulate_multi"):
