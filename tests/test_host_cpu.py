@@ -228,8 +228,8 @@ def test_two_rank_gloo_exact_replay_matches_single_process():
 
 
 def test_c_example_builds_against_the_header(tmp_path):
-    """examples/simulate.c and simulate_multi.c are plain C: the header must be C-clean and the library must link from gcc."""
-    for name in ("simulate", "simulate_multi"):
+    """examples/simulate.c, simulate_multi.c and exact_replay.c are plain C: the header must be C-clean and the library must link from gcc."""
+    for name in ("simulate", "simulate_multi", "exact_replay"):
         exe = tmp_path / name
         subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"),
                                "-o", str(exe), "-L", os.path.join(ROOT, "ldpc-lib_amd"), "-lldpc_hip",

@@ -372,3 +372,19 @@ def test_two_ranks_exact_replay(L, torch):
     for o in outs:
         line = [ln for ln in o.splitlines() if ln.startswith("RESULT")][0]
         assert json.loads(line.split(" ", 2)[2]) == want
+
+
+@pytest.mark.gpu
+def test_c_example_replays_the_headline_run(L, torch, tmp_path):
+    """examples/exact_replay.c: the exact-replay entry points from plain C -- cfg2, seed 1: 170 errored frames in 4001."""
+    import subprocess
+    from ldpc_testlib import GOLDEN_DIR
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "exact_replay")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "exact_replay.c"), "-o", exe,
+                           "-L", os.path.join(root, "ldpc-lib_amd"), "-lldpc_hip", "-Wl,-rpath," + os.path.join(root, "ldpc-lib_amd")])
+    out = subprocess.check_output([exe, os.path.join(GOLDEN_DIR, "h16x32_m126.txt"), "64", "3", "50", "2.0", "4000", "1"]).decode().split()
+    assert out[out.index("frames") + 1] == "4001" and out[out.index("errored") + 1] == "170", out
+    res = _oracle_sim(relift(load_base_matrix(), 64), 64, MS_DEC, 2.0, 50, 10**9, 4000, 1.0, 1)
+    # the state the example reports continues upstream's stream: its next word is the sequential loop's next word
+    assert int(out[out.index("undetected") + 1]) == res.nue
