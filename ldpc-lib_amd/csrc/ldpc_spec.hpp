@@ -1401,6 +1401,25 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
     }
 }
 
+// a / b for operands whose range is known: the instruction sequence the compiler emits for an fp64 division is
+//   v_div_scale (x2), v_rcp_f64, two Newton steps, q = a*r, e = fma(-b, q, a), v_div_fmas, v_div_fixup;
+// v_div_scale / v_div_fmas / v_div_fixup only act when an operand or the quotient is zero-denominator, infinite, NaN, denormal or
+// within ~2^53 of the exponent limits (ISA: V_DIV_SCALE_F64) -- otherwise they pass their input through and the result is
+// fma(e, r, q).  The probability-domain decoders divide quantities that are bounded away from all of that by construction
+// (messages clamped to [1e-4, 1 - 1e-4] resp. [1e-6, 1 - 1e-6], channel priors in [4e-18, 1 - 4e-18], column weights <= a few
+// dozen: numerators in [1e-300, 1e7] or exactly 0, denominators in [1e-7, 2]), so the three instructions are dropped: the SAME
+// eight remaining instructions, hence the same bits, 27 % fewer instructions per division.
+__device__ __forceinline__ double div_ranged(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double f = __fma_rn(-b, r, 1.0);
+    r = __fma_rn(r, f, r);
+    f = __fma_rn(-b, r, 1.0);
+    r = __fma_rn(r, f, r);
+    const double q = a * r;
+    const double e = __fma_rn(-b, q, a);
+    return __fma_rn(e, r, q);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // TDMP ("turbo-decoding message passing") sum-product in the probability domain -- upstream
 // tdmp_sum_prod_gf2_decod_qc_lm (decoders.cpp:2584-2744, map_bin :2191-2228), decoder id 7, the decoder_type of every
@@ -1481,7 +1500,7 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
                 constexpr int s = decltype(S)::value;
                 const double x = *reinterpret_cast<const double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M));
                 const double aa = Z[j][s];
-                double v = x * (1.0 - aa) / (aa + x - 2.0 * aa * x);        // :2686 rho = gamma - lambda
+                double v = div_ranged(x * (1.0 - aa), aa + x - 2.0 * aa * x);   // :2686 rho = gamma - lambda; the denominator is >= min(aa, 1 - aa) >= 1e-4
                 v = at_most(at_least(v, TT), 1 - TT);                        // :2694-2695
                 y[s] = v;
                 P[s] = 1 - 2 * v;                                            // map_bin :2206
@@ -1498,7 +1517,7 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
                 double v = q[s];
                 v = at_most(at_least(v, T), 1.0 - T);                        // :2703-2704
                 Z[j][s] = v;
-                const double g = y[s] * v / (1.0 - y[s] - v + 2 * y[s] * v);  // :2716 gamma = rho + lambda
+                const double g = div_ranged(y[s] * v, 1.0 - y[s] - v + 2 * y[s] * v);  // :2716 gamma = rho + lambda; denominator >= min(v, 1 - v) >= 1e-4
                 if (valid) *reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M)) = g;
             });
             if constexpr (W > 1) __syncthreads();
@@ -1642,15 +1661,15 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
                     P1 *= d[x];                                               // :2511-2512, rows ascending
                     P0 *= 1 - d[x];
                 });
-                const double sov = P1 / (P0 + P1);                            // :2519
+                const double sov = div_ranged(P1, P0 + P1);                   // :2519 (P1 >= 4e-18 * 1e-6^CW > 0)
                 so[q] = sov;
                 hb[k * M + t] = sov > 0.5;
                 static_for<0, CW>([&](auto X) {                               // :2540-2548
                     constexpr int x = decltype(X)::value;
                     int nn = t - V.cc[k][x]; if (nn < 0) nn += M;
-                    const double p1 = sov / d[x];
-                    const double p0 = (1 - sov) / (1 - d[x]);
-                    const double dd = p1 / (p1 + p0);
+                    const double p1 = div_ranged(sov, d[x]);                  // d in [1e-6, 1 - 1e-6]: map_bin of clamped states
+                    const double p0 = div_ranged(1 - sov, 1 - d[x]);
+                    const double dd = div_ranged(p1, p1 + p0);
                     *reinterpret_cast<double *>(stb + (size_t)V.ce[k][x] * M * 8 + nn * 8) = at_least(at_most(dd, 1.0 - 0.000001), 0.000001);
                 });
             }

@@ -36,8 +36,9 @@ for case in range(cases):
     if (H >= 0).sum(axis=1).max() > 8 and not GLOBAL:
         continue
     frames = 8 if M * nh > 20000 else 24 if M * nh > 2000 else 70
-    llr = np.concatenate([awgn_llr(H, M, s, 500 + case, frames // 2) for s in (2.0, 5.0)])
-    if "--sp" not in sys.argv:
+    snrs = tuple(float(x) for x in os.environ["SOAK_SNRS"].split(",")) if os.environ.get("SOAK_SNRS") else (2.0, 5.0)
+    llr = np.concatenate([awgn_llr(H, M, s, 500 + case, max(1, frames // len(snrs))) for s in snrs])
+    if "--sp" not in sys.argv or "--extremes" in sys.argv:
         llr[0, :3] = [0.0, -0.0, 40000.0]
     for dec_id in FAMILY:
         o = Oracle(H, M)
