@@ -1403,12 +1403,16 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
 
 // a / b for operands whose range is known: the instruction sequence the compiler emits for an fp64 division is
 //   v_div_scale (x2), v_rcp_f64, two Newton steps, q = a*r, e = fma(-b, q, a), v_div_fmas, v_div_fixup;
-// v_div_scale / v_div_fmas / v_div_fixup only act when an operand or the quotient is zero-denominator, infinite, NaN, denormal or
-// within ~2^53 of the exponent limits (ISA: V_DIV_SCALE_F64) -- otherwise they pass their input through and the result is
-// fma(e, r, q).  The probability-domain decoders divide quantities that are bounded away from all of that by construction
-// (messages clamped to [1e-4, 1 - 1e-4] resp. [1e-6, 1 - 1e-6], channel priors in [4e-18, 1 - 4e-18], column weights <= a few
-// dozen: numerators in [1e-300, 1e7] or exactly 0, denominators in [1e-7, 2]), so the three instructions are dropped: the SAME
-// eight remaining instructions, hence the same bits, 27 % fewer instructions per division.
+// v_div_scale / v_div_fmas / v_div_fixup only act when the denominator is zero, an operand is infinite / NaN / denormal, the
+// numerator is below 2^-969, or the exponents differ by 768 or more (ISA: V_DIV_SCALE_F64) -- otherwise they pass their input
+// through and the result is fma(e, r, q).  The probability-domain decoders divide quantities that are bounded away from all of
+// that by construction: messages are clamped to [1e-4, 1 - 1e-4] (TDMP) resp. [1e-6, 1 - 1e-6] (ASP), channel priors lie in
+// [4.2e-18, 1 - 4.2e-18] (LLR / 2 clamped to +-20), so a posterior or extrinsic probability is >= 4.2e-18 * clamp^(column weight):
+// >= 4e-274 for TDMP (column weight <= block rows <= 64) and >= 4e-258 for ASP with column weight <= 40 -- both far above
+// 2^-969 = 2e-292 -- and every denominator is >= the clamp bound (e.g. aa + x - 2 aa x >= min(aa, 1 - aa)) and <= 1e7.  A numerator
+// may be exactly 0 (1 - sov): 0 * r = 0, e = 0, result +0 as with the full sequence.  So the three instructions are dropped: the
+// SAME eight remaining instructions, hence the same bits, 27 % fewer instructions per division.  ASP columns heavier than 40
+// keep the compiler's division (div_if).
 __device__ __forceinline__ double div_ranged(double a, double b) {
     double r = __builtin_amdgcn_rcp(b);
     double f = __fma_rn(-b, r, 1.0);
@@ -1418,6 +1422,11 @@ __device__ __forceinline__ double div_ranged(double a, double b) {
     const double q = a * r;
     const double e = __fma_rn(-b, q, a);
     return __fma_rn(e, r, q);
+}
+template <bool RANGED>
+__device__ __forceinline__ double div_if(double a, double b) {
+    if constexpr (RANGED) return div_ranged(a, b);
+    else return a / b;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1434,6 +1443,7 @@ __device__ __forceinline__ double div_ranged(double a, double b) {
 template <class C>
 __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
     constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, W = (M + 63) / 64;
+    static_assert(RH <= 64, "tasp_body: div_ranged's lower bound on the probabilities assumes column weights <= 64");
     constexpr double T = 0.0001, TT = 0;                                   // :2597-2598
     extern __shared__ double lds[];                                         // [N] soft_out, then one flag word
     char *const ldsb = reinterpret_cast<char *>(lds);
@@ -1661,15 +1671,16 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
                     P1 *= d[x];                                               // :2511-2512, rows ascending
                     P0 *= 1 - d[x];
                 });
-                const double sov = div_ranged(P1, P0 + P1);                   // :2519 (P1 >= 4e-18 * 1e-6^CW > 0)
+                constexpr bool RD = CW <= 40;                                 // see div_ranged: P1 >= 4.2e-18 * 1e-6^CW
+                const double sov = div_if<RD>(P1, P0 + P1);                   // :2519
                 so[q] = sov;
                 hb[k * M + t] = sov > 0.5;
                 static_for<0, CW>([&](auto X) {                               // :2540-2548
                     constexpr int x = decltype(X)::value;
                     int nn = t - V.cc[k][x]; if (nn < 0) nn += M;
-                    const double p1 = div_ranged(sov, d[x]);                  // d in [1e-6, 1 - 1e-6]: map_bin of clamped states
-                    const double p0 = div_ranged(1 - sov, 1 - d[x]);
-                    const double dd = div_ranged(p1, p1 + p0);
+                    const double p1 = div_if<RD>(sov, d[x]);                  // d in [1e-6, 1 - 1e-6]: map_bin of clamped states
+                    const double p0 = div_if<RD>(1 - sov, 1 - d[x]);
+                    const double dd = div_if<RD>(p1, p1 + p0);
                     *reinterpret_cast<double *>(stb + (size_t)V.ce[k][x] * M * 8 + nn * 8) = at_least(at_most(dd, 1.0 - 0.000001), 0.000001);
                 });
             }
