@@ -29,6 +29,16 @@ def test_build_entry_point_and_abi_exports():
     assert lib.ldpc_hip_abi_version() == 3
 
 
+def test_jit_mode_switch():
+    """ldpc_hip_set_jit_mode: process-wide default (0 never / 1 inside ldpc_hip_open / 2 background), returns the previous mode"""
+    import ldpc_lib_amd
+    lib = ldpc_lib_amd.load_library()
+    assert lib.ldpc_hip_set_jit_mode(2) == 1          # the C-ABI's default: compile inside ldpc_hip_open
+    assert lib.ldpc_hip_set_jit_mode(0) == 2
+    assert lib.ldpc_hip_set_jit_mode(7) < 0 and b"ldpc_hip_set_jit_mode" in lib.ldpc_hip_last_error()
+    assert lib.ldpc_hip_set_jit_mode(1) == 0
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     if torch.cuda.is_available():
