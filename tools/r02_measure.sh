@@ -26,7 +26,7 @@ timeout -k 10 500 python tools/time_exact.py > gpurun_out/r02/r02_exact_replay.j
 python3 - <<'PY'
 import json
 d=json.load(open("gpurun_out/r02/r02_exact_replay.json"))
-for k in ("generator","mt_frames_B65536","decode_only_B65536","harness_device_noise","harness_host_noise"): print(k, {a:(round(b,4) if isinstance(b,float) else b) for a,b in d[k].items()})
+for k in ("generator","mt_frames_B65536","decode_only_B65536","harness_device_noise","harness_device_long_run_noise","harness_host_noise"): print(k, {a:(round(b,4) if isinstance(b,float) else b) for a,b in d[k].items()})
 for k,v in d["whole_call_latency_best_of_3"].items(): print(k, round(v["device"]["seconds"]*1e3,2), "ms device", round(v["host"]["seconds"]*1e3,2), "ms host")
 for k,v in d["code_search_like_loop_tasp_m64"].items(): print("search loop", k, "mean s/candidate", round(v["mean_seconds"],3), [round(p["seconds"],3) for p in v["candidates"]])
 PY

@@ -63,8 +63,8 @@ def main():
         del llr
     lib = _compat(ldpc_lib_amd)
     Hc = np.ascontiguousarray(H, dtype=np.int32)
-    for noise, nfr in (("device", args.frames), ("host", args.host_frames)):
-        os.environ["LDPC_HIP_EXACT_NOISE"] = noise
+    for noise, nfr in (("device", args.frames), ("device_long_run", 10 * args.frames), ("host", args.host_frames)):
+        os.environ["LDPC_HIP_EXACT_NOISE"] = noise.split("_")[0]
         res = (C.c_double * 7)()
         nxt = C.c_uint()
         t = time.perf_counter()
