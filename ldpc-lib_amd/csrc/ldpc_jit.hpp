@@ -239,6 +239,10 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         if (!started_) {
             started_ = true;
+            // hiprtc dlopen()s its compiler (comgr) at its first compile, and exit() runs handlers and library destructors newest
+            // first: compile something trivial NOW, so that the compiler's destructors are registered BEFORE the handler below --
+            // the handler then runs first and lets a compile that is in flight at exit finish while its compiler is still alive
+            warm_up();
             th_ = std::thread([this] { run(); });
             atexit([] { Worker::instance().stop(); });
         }
@@ -255,6 +259,16 @@ public:
     }
 
 private:
+    static void warm_up() {
+        std::string err;
+        Rtc *r = rtc(err);
+        if (!r) return;
+        hiprtcProgram prog = nullptr;
+        if (r->CreateProgram(&prog, "extern \"C\" __global__ void ldpc_jit_warm_up() {}\n", "warm_up.hip", 0, nullptr, nullptr) != 0) return;
+        const char *opts[] = {"--offload-arch=gfx950", "-O1"};
+        (void)r->CompileProgram(prog, 2, opts);
+        r->DestroyProgram(&prog);
+    }
     void run() {
         for (;;) {
             std::shared_ptr<Job> j;
