@@ -333,7 +333,7 @@ std::pair<double, double> bp_simulation_throughput_t(int q_mod, Mat const &H, in
                                                      int modulation_type, int permutation_type, int permutation_block, int permutation_inter,
                                                      int punctured_blocks, int show_process, unsigned long long seed,
                                                      const std::vector<int> &devices, SimCounters *counters_out = nullptr,
-                                                     long long batch_per_gpu = 16384, const unsigned char *codewords = nullptr, int ncw = 0) {
+                                                     long long batch_per_gpu = 65536, const unsigned char *codewords = nullptr, int ncw = 0) {
     if (q_mod != 2) Env::fail("bp_simulation: only binary codes (q_mod == 2) are built in ldpc-lib_amd");
     if (devices.empty()) Env::fail("bp_simulation: empty device list");
     const int b = H.n_rows(), c = H.n_cols(), M = tailbite_length;
