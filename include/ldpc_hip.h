@@ -170,6 +170,15 @@ int ldpc_hip_qam_demod_dev(int Q, double T, double sigma, const double *d_x, lon
  * the result (it zeroes the codeword, :568); this entry exists for callers that do and for the sign-symmetry tests. */
 int ldpc_hip_encode_host(int rh, int nh, int M, const int16_t *hd, const uint8_t *info_bits, uint8_t *codeword);
 
+/* The same encoder on the device (csrc/ldpc_encode.hpp): d_info_bits [B][(nh-rh)*M] bytes 0/1 -> d_codewords [B][nh*M] bytes, parity
+ * first, identical to ldpc_hip_encode_host.  Base matrices with one dual-diagonal block (what upstream's search produces); matrices
+ * made of several blocks (bp_simulation.cpp:142-191) are refused here and stay with the host encoder. */
+int ldpc_hip_encode_dev(ldpc_hip_ctx *ctx, const uint8_t *d_info_bits, long long B, uint8_t *d_codewords, void *stream);
+/* A table of ncw random codewords made on the device (information bits from Philox4x32-10 keyed by seed and codeword index, then the
+ * device encoder) and installed like ldpc_hip_set_codewords: global frame f carries codeword f % ncw.  ncw == 0 returns to the all-zero
+ * codeword.  (What upstream's random_codeword() is for, bp_simulation.cpp:142-191, before :568 zeroes its result.) */
+int ldpc_hip_set_random_codewords(ldpc_hip_ctx *ctx, uint64_t seed, int ncw);
+
 /* Bit interleavers of the simulation chain (Permutations_Open / Permutation_Init / Permutation,
  * direct_inverse_perm.cpp:139-900; permutation_type of bp_simulation.h:21-23): mode 0 identity, 1 random, 2 deterministic,
  * 3 block random (block_size), 4 interleaved random (step_size); halfmlog = 1 (BPSK / QAM4), 2, 3, 4 (QAM16 / 64 / 256).
@@ -251,6 +260,7 @@ ldpc_hip_ctx *ldpc_hip_multi_ctx(ldpc_hip_multi *m, int shard);      /* per-shar
 const char *ldpc_hip_multi_reduction(const ldpc_hip_multi *m);      /* "rccl" or "host" */
 int ldpc_hip_multi_set_interleaver(ldpc_hip_multi *m, int permutation_type, int permutation_block, int permutation_inter);
 int ldpc_hip_multi_set_codewords(ldpc_hip_multi *m, const uint8_t *codewords, int ncw);
+int ldpc_hip_multi_set_random_codewords(ldpc_hip_multi *m, uint64_t seed, int ncw);
 int ldpc_hip_simulate_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha,
                             uint64_t seed, long long first_frame, long long B, long long batch, unsigned long long counters[4],
                             unsigned long long *sum_abs_iters);

@@ -116,6 +116,9 @@ def load_library():
     lib.ldpc_hip_frames_multi.argtypes = [vp, f64, i32, i32, i32, f64, u64, i64, i64, i64, vp, vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.ldpc_hip_decode_host_multi.argtypes = [vp, vp, i64, i32, i32, f64, vp, vp, i32]
     lib.ldpc_hip_set_jit_mode.argtypes = [i32]
+    lib.ldpc_hip_encode_dev.argtypes = [vp, vp, i64, vp, vp]
+    lib.ldpc_hip_set_random_codewords.argtypes = [vp, u64, i32]
+    lib.ldpc_hip_multi_set_random_codewords.argtypes = [vp, u64, i32]
     lib.ldpc_hip_mt_jump_host.argtypes = [vp, i32, vp]
     lib.ldpc_hip_mt_set_state.argtypes = [vp, vp, i32]
     lib.ldpc_hip_mt_get_state.argtypes = [vp, vp, C.POINTER(i32)]
@@ -195,6 +198,20 @@ class LdpcHip:
             return
         cw = np.ascontiguousarray(codewords, dtype=np.uint8).reshape(-1, self.N)
         _check(self.lib, self.lib.ldpc_hip_set_codewords(self.h, cw.ctypes.data, cw.shape[0]), "ldpc_hip_set_codewords")
+
+    def set_random_codewords(self, seed, ncw):
+        """ncw random codewords made on the device (Philox information bits + the device encoder); frame f carries codeword f % ncw."""
+        _check(self.lib, self.lib.ldpc_hip_set_random_codewords(self.h, int(seed), int(ncw)), "ldpc_hip_set_random_codewords")
+
+    def encode_dev(self, info_bits, stream=None):
+        """uint8 CUDA tensor [B, (nh-rh)*M] of 0/1 -> codewords uint8 [B, N] (parity first), on the device."""
+        import torch
+        info = info_bits.contiguous()
+        assert info.dtype == torch.uint8 and info.shape[1] == self.N - self.R
+        out = torch.empty((info.shape[0], self.N), dtype=torch.uint8, device=info.device)
+        rc = self.lib.ldpc_hip_encode_dev(self.h, C.c_void_p(info.data_ptr()), int(info.shape[0]), C.c_void_p(out.data_ptr()), _stream_ptr(stream))
+        _check(self.lib, rc, "ldpc_hip_encode_dev")
+        return out
 
     def __del__(self):
         try:

@@ -27,6 +27,7 @@
 #include "code_appendix_c_m64.hpp"
 #include "ldpc_sumprod.hpp"
 #include "ldpc_mt.hpp"
+#include "ldpc_encode.hpp"
 
 namespace {
 
@@ -229,7 +230,9 @@ struct ldpc_hip_ctx {
     // wiring, all-zero codeword and permutation_type 0
     int perm_type = 0, perm_block = 128, perm_inter = 1;
     std::vector<int> hd_int;              // the base matrix as opened (the interleaver builder reads it)
-    std::vector<uint8_t> codewords;       // [ncw][N] 0/1, decoder order
+    std::vector<uint8_t> codewords;       // [ncw][N] 0/1, decoder order (ldpc_hip_set_codewords)
+    uint8_t *d_cw_bytes = nullptr;        // [ncw][N] the same table when it was produced on the device (ldpc_hip_set_random_codewords)
+    int *d_hd_enc = nullptr;              // [rh][nh] base matrix for the device encoder
     int ncw = 0;
     int chain_mod = -1;                   // modulation_type the device-side chain tables below were built for (-1: stale)
     int chain_ntx = 0;
@@ -589,6 +592,8 @@ void ldpc_hip_close(ldpc_hip_ctx *c) {
     if (c->d_tx) (void)hipFree(c->d_tx);
     if (c->d_cw_packed) (void)hipFree(c->d_cw_packed);
     if (c->d_scatter) (void)hipFree(c->d_scatter);
+    if (c->d_cw_bytes) (void)hipFree(c->d_cw_bytes);
+    if (c->d_hd_enc) (void)hipFree(c->d_hd_enc);
     ldpc_mt::release(c->mt);
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete c;
@@ -870,7 +875,22 @@ static int prepare_chain(ldpc_hip_ctx *c, int modulation_type) {
         HIP_TRY(hipMalloc(&c->d_scatter, sizeof(int32_t) * (size_t)N));
         HIP_TRY(hipMemcpy(c->d_scatter, scatter.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
     }
-    if (c->ncw > 0) {
+    if (c->ncw > 0 && c->d_cw_bytes) {   // the table lives on the device: transmit order and packed words by kernels
+        int32_t *d_direct = nullptr;
+        if (!direct.empty()) {
+            HIP_TRY(hipMalloc(&d_direct, sizeof(int32_t) * (size_t)N));
+            HIP_TRY(hipMemcpy(d_direct, direct.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
+        }
+        HIP_TRY(hipMalloc(&c->d_tx, (size_t)c->ncw * ntx));
+        HIP_TRY(hipMalloc(&c->d_cw_packed, sizeof(uint32_t) * (size_t)c->ncw * c->hard_words));
+        ldpc::CwOrderArgs oa{c->d_cw_bytes, c->d_tx, d_direct, c->ncw, N, ntx};
+        ldpc::CwPackArgs pa{c->d_cw_bytes, c->d_cw_packed, c->ncw, N, c->hard_words};
+        hipLaunchKernelGGL(ldpc::cw_channel_order_kernel, dim3(1024), dim3(256), 0, nullptr, oa);
+        hipLaunchKernelGGL(ldpc::cw_pack_kernel, dim3(1024), dim3(256), 0, nullptr, pa);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        if (d_direct) (void)hipFree(d_direct);
+    } else if (c->ncw > 0) {
         std::vector<uint8_t> tx((size_t)c->ncw * ntx, 0);
         std::vector<uint32_t> packed((size_t)c->ncw * c->hard_words, 0u);
         for (int w = 0; w < c->ncw; ++w) {
@@ -907,6 +927,82 @@ int ldpc_hip_set_interleaver(ldpc_hip_ctx *c, int permutation_type, int permutat
 int ldpc_hip_set_codewords(ldpc_hip_ctx *c, const uint8_t *codewords, int ncw) {
     if (!c || ncw < 0 || (ncw > 0 && !codewords)) return fail(LDPC_HIP_EINVAL, "ldpc_hip_set_codewords: bad argument");
     c->codewords.assign(codewords, codewords + (size_t)ncw * c->N);
+    if (c->d_cw_bytes) { (void)hipSetDevice(c->device); (void)hipFree(c->d_cw_bytes); c->d_cw_bytes = nullptr; }
+    c->ncw = ncw;
+    c->chain_mod = -1;
+    return 0;
+}
+
+// the device encoder's view of the code: one dual-diagonal block (encoder.h encode() with brk = {0, b}), validated by encoding
+// one word on the host first
+static int encoder_setup(ldpc_hip_ctx *c, ldpc::EncodeArgs &ea) {
+    const int b = c->rh, cc = c->nh, M = c->M;
+    const int *mx = c->hd_int.data();
+    auto at = [&](int i, int j) { return mx[i * cc + j]; };
+    for (int i = 1; i + 1 < b; ++i) {   // block boundaries of bp_simulation.cpp:143-156: several blocks stay with the host encoder
+        const bool bi = at(i, i) >= 0 && at(i + 1, i) >= 0 && at(i, i - 1) < 0;
+        const bool uni = i > 1 && at(i, i) >= 0 && at(i + 1, i) < 0 && at(i, i - 1) < 0 && at(i - 1, i - 1) >= 0 && at(i - 1, i - 2) >= 0;
+        if (bi || uni) return fail(LDPC_HIP_EUNSUPPORTED, "the device encoder takes base matrices with one dual-diagonal block; this one has several: encode on the host (ldpc_hip_encode_host) and use ldpc_hip_set_codewords");
+    }
+    if (cc <= b) return fail(LDPC_HIP_EUNSUPPORTED, "no information part to encode");
+    const size_t lds = (size_t)c->N + (size_t)c->R + (size_t)M;
+    if (lds > 150 * 1024) return fail(LDPC_HIP_EUNSUPPORTED, "code length %d is beyond the device encoder's LDS image", c->N);
+    std::vector<uint8_t> probe((size_t)(cc - b) * M);
+    for (size_t i = 0; i < probe.size(); ++i) probe[i] = (uint8_t)((i * 2654435761u >> 7) & 1u);
+    ldpc::BitVec cw;
+    const int rc = ldpc::encode(mx, b, cc, M, probe.data(), cw);
+    if (rc != 0) return fail(LDPC_HIP_EUNSUPPORTED, "this base matrix is not encodable by the dual-diagonal encoder (code %d)", rc);
+    ea.b = b; ea.c = cc; ea.M = M;
+    ea.single = b > 1 ? (at(1, 0) < 0) : 1;                                // bp_simulation.cpp:33
+    int p = 0;
+    while (p < b && at(p, b - 1) <= 0) ++p;                                 // :36-39
+    ea.p = p < b ? p : 0;
+    if (!c->d_hd_enc) {
+        HIP_TRY(hipMalloc(&c->d_hd_enc, sizeof(int) * (size_t)b * cc));
+        HIP_TRY(hipMemcpy(c->d_hd_enc, mx, sizeof(int) * (size_t)b * cc, hipMemcpyHostToDevice));
+    }
+    ea.hd = c->d_hd_enc;
+    return 0;
+}
+
+static int encode_launch(ldpc_hip_ctx *c, ldpc::EncodeArgs ea, const uint8_t *d_info, long long B, uint8_t *d_cw, hipStream_t st) {
+    ea.info = d_info; ea.cw = d_cw; ea.B = B;
+    const size_t lds = (size_t)c->N + (size_t)c->R + (size_t)c->M;
+    if (int rc = set_lds_limit(reinterpret_cast<const void *>(ldpc::qc_encode_kernel), lds)) return rc;
+    const long long grid = B < 256 * 8 ? B : 256 * 8;
+    hipLaunchKernelGGL(ldpc::qc_encode_kernel, dim3((unsigned)grid), dim3(256), lds, st, ea);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ldpc_hip_encode_dev(ldpc_hip_ctx *c, const uint8_t *d_info_bits, long long B, uint8_t *d_codewords, void *stream_) {
+    if (!c || B < 0 || (B > 0 && (!d_info_bits || !d_codewords))) return fail(LDPC_HIP_EINVAL, "ldpc_hip_encode_dev: bad argument");
+    if (B == 0) return 0;
+    if (int rc = set_device(c)) return rc;
+    ldpc::EncodeArgs ea{};
+    if (int rc = encoder_setup(c, ea)) return rc;
+    return encode_launch(c, ea, d_info_bits, B, d_codewords, (hipStream_t)stream_);
+}
+
+int ldpc_hip_set_random_codewords(ldpc_hip_ctx *c, uint64_t seed, int ncw) {
+    if (!c || ncw < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_set_random_codewords: bad argument");
+    if (int rc = set_device(c)) return rc;
+    if (ncw == 0) return ldpc_hip_set_codewords(c, nullptr, 0);
+    ldpc::EncodeArgs ea{};
+    if (int rc = encoder_setup(c, ea)) return rc;
+    const int K = c->N - c->R;
+    uint8_t *d_info = nullptr, *d_cw = nullptr;
+    HIP_TRY(hipMalloc(&d_info, (size_t)ncw * K));
+    if (hipMalloc(&d_cw, (size_t)ncw * c->N) != hipSuccess) { (void)hipFree(d_info); return fail(LDPC_HIP_ENOMEM, "ldpc_hip_set_random_codewords: out of device memory"); }
+    ldpc::RandomInfoArgs ra{d_info, ncw, 0, K, seed};
+    hipLaunchKernelGGL(ldpc::random_info_kernel, dim3(1024), dim3(256), 0, nullptr, ra);
+    int rc = encode_launch(c, ea, d_info, ncw, d_cw, nullptr);
+    if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = fail(LDPC_HIP_EHIP, "ldpc_hip_set_random_codewords: %s", hipGetErrorString(hipGetLastError()));
+    (void)hipFree(d_info);
+    if (rc) { (void)hipFree(d_cw); return rc; }
+    if (c->d_cw_bytes) (void)hipFree(c->d_cw_bytes);
+    c->d_cw_bytes = d_cw;
+    c->codewords.clear();
     c->ncw = ncw;
     c->chain_mod = -1;
     return 0;

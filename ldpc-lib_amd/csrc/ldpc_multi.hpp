@@ -231,6 +231,12 @@ int ldpc_hip_multi_set_codewords(ldpc_hip_multi *m, const uint8_t *codewords, in
     return 0;
 }
 
+int ldpc_hip_multi_set_random_codewords(ldpc_hip_multi *m, uint64_t seed, int ncw) {
+    if (!m) return fail(LDPC_HIP_EINVAL, "null multi context");
+    for (ldpc_hip_ctx *c : m->shard) if (int rc = ldpc_hip_set_random_codewords(c, seed, ncw)) return rc;   // the same table on every shard
+    return 0;
+}
+
 int ldpc_hip_simulate_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha,
                             uint64_t seed, long long first_frame, long long B, long long batch, unsigned long long counters[4],
                             unsigned long long *sum_abs_iters) {

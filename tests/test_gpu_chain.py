@@ -392,3 +392,61 @@ def test_multi_gpu_c_example_runs(L, tmp_path):
     row = [ln for ln in out.splitlines() if ln.startswith("Eb/N0")][0].split()
     fer = float(row[row.index("FER") + 1])
     assert int(row[row.index("frames") + 1]) == 60000 and 0.02 < fer < 0.07, out
+
+
+# ---- the encoder on the device (csrc/ldpc_encode.hpp) -----------------------------------------------------------------------------
+@pytest.mark.parametrize("M", [1, 7, 64, 126, 512])
+def test_device_encoder_equals_the_host_encoder(L, torch, M):
+    """ldpc_hip_encode_dev == ldpc_hip_encode_host (upstream's qc_encode restated), bit for bit, and every word is a codeword"""
+    from ldpc_lib_amd.binding import encode
+    H = relift(load_base_matrix(), M)
+    rh, nh = H.shape
+    rng = np.random.RandomState(1000 + M)
+    info = rng.randint(0, 2, size=(37, (nh - rh) * M)).astype(np.uint8)
+    with L.LdpcHip(MS_DEC, H, M) as dec:
+        got = dec.encode_dev(torch.from_numpy(info).cuda()).cpu().numpy()
+    want = np.stack([encode(H, M, row) for row in info])
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[:, rh * M:], info)                      # systematic
+    for w in got[:5]:                                                  # H c = 0 (bp_simulation.cpp:87-116)
+        for i in range(rh):
+            s = np.zeros(M, dtype=np.uint8)
+            for j in range(nh):
+                if H[i, j] >= 0:
+                    s ^= np.roll(w[j * M:(j + 1) * M], -int(H[i, j]) % M)
+            assert not s.any()
+
+
+def test_device_encoder_refuses_what_it_does_not_cover(L, torch):
+    H = relift(load_base_matrix(), 64).copy()
+    H[3, 2] = -1                      # breaks the double diagonal: not encodable at all
+    with L.LdpcHip(MS_DEC, H, 64) as dec:
+        with pytest.raises(L.LdpcHipError):
+            dec.set_random_codewords(1, 16)
+
+
+@pytest.mark.parametrize("mod,perm,snr", [(0, 0, 9.0), (2, 3, 14.0), (1, 1, 9.0)])
+def test_random_codeword_table_from_the_device(L, torch, mod, perm, snr):
+    """ldpc_hip_set_random_codewords: table, transmit order and packed reference words are all made on the device.  At a high
+    Eb/N0 every frame must decode to ITS codeword (zero errors against the sent words -- any inconsistency between the three would
+    show as errors), the codewords differ from frame to frame, and the same seed gives the same table on a second context."""
+    M = 64
+    H = relift(load_base_matrix(), M)
+    with L.LdpcHip(MS_DEC, H, M) as dec:
+        if perm:
+            dec.set_interleaver(perm, 64, 1)
+        dec.set_random_codewords(77, 300)
+        s = dec.simulate(snr, 50, seed=5, first_frame=0, B=1500, modulation=mod)
+        assert s["frames"] == 1500 and s["nde"] == 0 and s["nse"] == 0
+        llr = dec.awgn_llr(snr, 5, 0, 600, modulation=mod)
+        hard, iters, _ = dec.decode(llr, 50)
+        bits = unpack_bits(hard.cpu().numpy().view(np.uint32), dec.N)
+        assert np.array_equal(bits[:300], bits[300:600])               # frame f carries codeword f % 300
+        assert len({row.tobytes() for row in bits[:300]}) == 300 and bits[:300].mean() > 0.4
+        with L.LdpcHip(MS_DEC, H, M) as dec2:
+            dec2.set_random_codewords(77, 300)
+            hard2, _, _ = dec2.decode(dec2.awgn_llr(snr, 5, 0, 300, modulation=0), 50)
+            assert np.array_equal(unpack_bits(hard2.cpu().numpy().view(np.uint32), dec.N), bits[:300])
+        dec.set_random_codewords(0, 0)                                  # back to upstream's all-zero codeword
+        s = dec.simulate(snr, 50, seed=5, first_frame=0, B=200, modulation=mod)
+        assert s["nde"] == 0
