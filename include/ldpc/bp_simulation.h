@@ -325,7 +325,8 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
 
 // Throughput mode.  Same arguments and return value as bp_simulation(); differences from exact-replay mode: the noise is the
 // device-side Philox stream (seed), every modulation_type 0..4 is available (QAM16+ as the evidently intended chain), and
-// `codewords` (optional, [ncw][n] 0/1 bytes) are really transmitted.  The stopping rule is upstream's, frame by frame in global
+// `codewords` (optional, [ncw][n] 0/1 bytes) are really transmitted; ncw > 0 with codewords == nullptr transmits ncw random codewords
+// encoded on the device (ldpc_hip_set_random_codewords).  The stopping rule is upstream's, frame by frame in global
 // frame order (:591, :805-823), so the result equals a sequential loop over the same noise whatever the batch size or GPU count.
 template <class Mat, class Env>
 std::pair<double, double> bp_simulation_throughput_t(int q_mod, Mat const &H, int tailbite_length, int max_iterations, int n_frame_errors,
@@ -346,7 +347,8 @@ std::pair<double, double> bp_simulation_throughput_t(int q_mod, Mat const &H, in
     if (jit_before >= 0) (void)ldpc_hip_set_jit_mode(jit_before);
     if (open_rc != 0) Env::fail(ldpc_hip_last_error());
     if (ldpc_hip_multi_set_interleaver(m, permutation_type, permutation_block, permutation_inter) != 0) Env::fail(ldpc_hip_last_error());
-    if (ncw > 0 && ldpc_hip_multi_set_codewords(m, codewords, ncw) != 0) Env::fail(ldpc_hip_last_error());
+    if (ncw > 0 && codewords && ldpc_hip_multi_set_codewords(m, codewords, ncw) != 0) Env::fail(ldpc_hip_last_error());
+    if (ncw > 0 && !codewords && ldpc_hip_multi_set_random_codewords(m, seed, ncw) != 0) Env::fail(ldpc_hip_last_error());   // made on the device
     const int nsh = (int)devices.size();
     long long nse = 0, nue = 0, nde = 0, experiment = 0, sum_abs_iters = 0, first = 0;
     std::vector<int32_t> info, iters;

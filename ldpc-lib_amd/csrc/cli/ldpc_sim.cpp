@@ -48,11 +48,13 @@ struct Pair { double ber, fer; };
 
 int main(int argc, char **argv) {
     bool throughput = false;
+    int random_codewords = 0;   // --throughput only: transmit this many random codewords encoded on the device instead of the all-zero word
     int device = 0;
     std::string devices_arg;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--throughput")) throughput = true;
+        else if (!strcmp(argv[i], "--random-codewords") && i + 1 < argc) random_codewords = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices_arg = argv[++i];
         else pos.push_back(argv[i]);
@@ -78,7 +80,7 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (pos.size() != 3 || pos[0] != "simulation")
-        die("usage: ldpc_sim simulation <scenario file name> <result file name> [--throughput] [--device N | --devices 0,1,.. | --devices all]\n"
+        die("usage: ldpc_sim simulation <scenario file name> <result file name> [--throughput [--random-codewords N]] [--device N | --devices 0,1,.. | --devices all]\n"
             "       ldpc_sim jsonx <in.jsonx> <out.jsonx>        re-emit in canonical form\n"
             "       ldpc_sim jsonx-get <in.jsonx> <path/to/field>  print one value (falls back to 'defaults' records)");
 
@@ -138,7 +140,8 @@ int main(int argc, char **argv) {
                 if (throughput) {
                     const std::pair<double, double> p = ldpc::bp_simulation_throughput_t<ldpc::Matrix, ldpc::OwnRngEnv>(
                         2, H, lifting, iterations, num_frame_errors, num_experiments, snrs[s], error_rate_threshold, decoder_type, modulation_type,
-                        permutation_type, permutation_block, permutation_inter, punctured_blocks, 0, (unsigned long long)seed, devices);
+                        permutation_type, permutation_block, permutation_inter, punctured_blocks, 0, (unsigned long long)seed, devices, nullptr, 65536, nullptr,
+                        random_codewords);
                     res = {p.first, p.second};
                 } else {
                     ldpc::initial_random_seed = seed;

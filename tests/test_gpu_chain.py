@@ -450,3 +450,27 @@ def test_random_codeword_table_from_the_device(L, torch, mod, perm, snr):
         dec.set_random_codewords(0, 0)                                  # back to upstream's all-zero codeword
         s = dec.simulate(snr, 50, seed=5, first_frame=0, B=200, modulation=mod)
         assert s["nde"] == 0
+
+
+def test_ldpc_sim_with_codewords_encoded_on_the_device(L, torch, tmp_path):
+    """`ldpc_sim simulation --throughput --random-codewords 128`: errors are counted against 128 different sent words made on the
+    device; for BPSK the code's symmetry makes the FER of the min-sum points statistically the all-zero run's (not identical: the same
+    noise sample hits a different transmitted sign)."""
+    import subprocess
+    from test_gpu_parity import _compat_lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _compat_lib(L)
+    exe = os.path.join(root, "ldpc-lib_amd", "ldpc_sim")
+    src = open(os.path.join(root, "examples", "simulation_appendix_c.jsonx")).read().replace("num_codewords = 2000", "num_codewords = 40000")
+    scen = tmp_path / "scen.jsonx"
+    scen.write_text(src)
+    fers = []
+    for extra in ([], ["--random-codewords", "128"]):
+        out = str(tmp_path / ("res%d.jsonx" % len(fers)))
+        subprocess.check_call([exe, "simulation", str(scen), out, "--throughput"] + extra, stdout=subprocess.DEVNULL)
+        get = lambda path, o=out: subprocess.check_output([exe, "jsonx-get", o, path], text=True).strip()
+        assert int(get("results/3/_decoder_type")) == MS_DEC
+        fers.append([float(x) for x in get("results/3/simulation_logs/0/FER").replace("array {", "").replace("}", "").split()])
+    assert fers[0] != fers[1]                                   # other words were sent
+    for a, b in zip(*fers):                                      # 40001 frames per point: sd of the difference ~ 0.0014 at FER 0.04
+        assert a > 0 and abs(a - b) < 0.007, fers
