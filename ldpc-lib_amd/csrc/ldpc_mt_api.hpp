@@ -110,6 +110,7 @@ int mt_llr_rows(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctur
     a.punct_val = (c->decoder_id == LDPC_HIP_SP_DEC || c->decoder_id == LDPC_HIP_TASP_DEC || c->decoder_id == LDPC_HIP_ASP_DEC) ? 0.0 : 0.5;  // :700 (sic)
     const long long per_round = (long long)(kRoundItems / (unsigned long long)c->N) > 0 ? (long long)(kRoundItems / (unsigned long long)c->N) : 1;
     long long done = 0;
+    int stalled = 0;
     while (done < B) {
         const long long fr = B - done < per_round ? B - done : per_round;
         const long long r_lo = lo > done ? lo : done, r_hi = hi < done + fr ? hi : done + fr;
@@ -121,6 +122,9 @@ int mt_llr_rows(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctur
         const long long fdone = (long long)(emitted / (unsigned long long)c->N);
         done += fdone;
         m.frames_taken += fdone;
+        // a round covers its frames with an 8-sigma margin; one that completes NO frame twice in a row means something is broken
+        stalled = fdone == 0 ? stalled + 1 : 0;
+        if (stalled >= 2) return fail(LDPC_HIP_EHIP, "the exact-replay generator made no progress (frame of %d samples)", c->N);
     }
     return 0;
 }
@@ -200,6 +204,7 @@ int ldpc_hip_mt_normal_dev(ldpc_hip_ctx *c, long long count, double *d_out, void
     if (int rc = set_device(c)) return rc;
     hipStream_t st = (hipStream_t)stream_;
     long long done = 0;
+    int stalled = 0;
     while (done < count) {
         const unsigned long long want = (unsigned long long)(count - done) < ldpc_mt::kRoundItems ? (unsigned long long)(count - done) : ldpc_mt::kRoundItems;
         ldpc_mt::PolarArgs a{};
@@ -207,6 +212,8 @@ int ldpc_hip_mt_normal_dev(ldpc_hip_ctx *c, long long count, double *d_out, void
         unsigned long long emitted = 0;
         if (int rc = mt_round(c, want, a, &emitted, st)) return rc;
         done += (long long)emitted;
+        stalled = emitted == 0 ? stalled + 1 : 0;
+        if (stalled >= 2) return fail(LDPC_HIP_EHIP, "the exact-replay generator made no progress");
     }
     return 0;
 }
