@@ -871,7 +871,9 @@ def test_background_specialisation_changes_tier_in_flight(L, torch, tmp_path, mo
         hard, iters, _ = dec.decode(x, maxit)
         assert "hiprtc" in dec.last_launch()
         assert np.array_equal(iters.cpu().numpy(), it_ref) and np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
-    assert t_open < 1.0 or t_open < 0.5 * t_jit, (t_open, t_jit)     # opening did not include the compile
+    # (that ldpc_hip_open did not wait for the compile is what `first_tier in dec.kernel_name` right after it shows; no wall-clock
+    # assertion: the first background job also loads hiprtc and its compiler, which takes a second on a cold box)
+    del t_open, t_jit
     with L.LdpcHip(dec_id, H, 64) as dec:
         assert "hiprtc" in dec.kernel_name                            # process cache
 
