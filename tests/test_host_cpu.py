@@ -29,6 +29,15 @@ def test_build_entry_point_and_abi_exports():
     assert lib.ldpc_hip_abi_version() == 3
 
 
+def test_generator_state_conversion(tmp_path):
+    """include/ldpc/bp_simulation.h: std::mt19937 <-> (624 words, next index), every block position incl. the freshly seeded one
+    (tests/cpp/mt_state_roundtrip.cpp; host only)"""
+    exe = tmp_path / "mt_rt"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "mt_state_roundtrip.cpp"),
+                           "-o", str(exe), "-L", os.path.join(ROOT, "ldpc-lib_amd"), "-lldpc_hip", "-Wl,-rpath," + os.path.join(ROOT, "ldpc-lib_amd")])
+    assert subprocess.check_output([str(exe)], text=True).strip() == "ok"
+
+
 def test_jit_mode_switch():
     """ldpc_hip_set_jit_mode: process-wide default (0 never / 1 inside ldpc_hip_open / 2 background), returns the previous mode"""
     import ldpc_lib_amd
