@@ -1,9 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- decoded frames/s of the MI355X min-sum path on BASELINE.json's headline configuration.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: this process starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+Two multi-GPU routes are timed, on the same workload:
+  value / ms_per_step   one process per GPU, torch.distributed over RCCL: decode + count + all-reduce of the 5 counters per step,
+                        barrier + synchronize on both sides of the K steps, MAX over ranks (the driver's contract);
+  abi_multi             north_star's route: ONE C/C++-style host process, ldpc_hip_open_multi(devices 0..N-1) -- a context, a HIP
+                        stream and a host thread per GPU inside libldpc_hip.so -- and ldpc_hip_decode_count_multi per step with ONE
+                        grouped ncclAllReduce of 5 x uint64 over xGMI.  Runs in a fresh child process after the ranks are gone.
 
 One "step" = one pass of the hot path over one batch already resident in HBM: ldpc_hip_decode_dev (min-sum, alpha 0.8,
 max 50 iterations) on 65536 frames/GPU of the (2048,1024) QC-LDPC code (BASELINE configs[1]) + the error-counter kernel
@@ -205,6 +212,7 @@ def cpu_baseline(H, seconds_budget=12.0):
     cores = max(1, min(os.cpu_count() or 1, 32))
     probe = awgn_llr(H, M, WORST_SNR, 1, 8)
     dec = Reference(MS_DEC, H, M) if kind == "reference" else Oracle(H, M)
+    dec.decode(MS_DEC, probe, MAXITER, 0)   # cold pass (page-in, first-touch): not timed, the sample is sized from the warm one
     t0 = time.perf_counter()
     dec.decode(MS_DEC, probe, MAXITER, 0)
     per_frame = (time.perf_counter() - t0) / 8
@@ -244,6 +252,132 @@ def cpu_baseline(H, seconds_budget=12.0):
     }
 
 
+def abi_multi_leg(n, steps, warmup, frames):
+    """north_star's multi-GPU route, timed: one host process, ldpc_hip_open_multi over n devices (a context + HIP stream + host
+    thread per GPU inside the library), per step ldpc_hip_decode_count_multi on batches resident in HBM = min-sum decode + error
+    count on every GPU, then ONE grouped RCCL all-reduce of the five uint64 counters.  The call is synchronous (the counters come
+    back to the host), so wall time around K calls is the whole-job time.  With fewer GPUs than shards (rehearsal on a one-GPU box)
+    shards share devices and the counters are summed on the host -- `reduction` says which."""
+    import torch
+
+    import ldpc_lib_amd
+    from ldpc_testlib import load_base_matrix, relift
+    H = relift(load_base_matrix(), M)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise RuntimeError("no GPU")
+    devices = [i % ndev for i in range(n)]
+    with ldpc_lib_amd.LdpcHipMulti(DEC_MS, H, M, devices) as m:
+        nb = max(1, min(steps, 4))
+        while nb > 1 and nb * frames * m.N * 8 * max(1, -(-n // ndev)) > 24e9:
+            nb -= 1
+        batches = []
+        for s in range(nb):   # distinct frames per step and shard: global frame index = (s*n + i)*frames + f
+            row = []
+            for i, d in enumerate(devices):
+                t = torch.empty((frames, m.N), dtype=torch.float64, device=f"cuda:{d}")
+                m.channel_llr(i, t, WORST_SNR, 1, (s * n + i) * frames)
+                row.append(t)
+            batches.append(row)
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        for s in range(warmup):
+            m.decode_count(batches[s % nb], MAXITER, first_frame=(s % nb) * n * frames, alpha=ALPHA)
+        tot = {"nse": 0, "nde": 0, "nue": 0, "frames": 0, "sum_abs_iters": 0}
+        t0 = time.perf_counter()
+        for s in range(steps):
+            c = m.decode_count(batches[s % nb], MAXITER, first_frame=(s % nb) * n * frames, alpha=ALPHA)
+            for k in tot:
+                tot[k] += c[k]
+        el = time.perf_counter() - t0
+        assert tot["frames"] == frames * n * steps, (tot, frames, n, steps)
+        return {
+            "what": "one host process, ldpc_hip_open_multi + ldpc_hip_decode_count_multi (csrc/ldpc_multi.hpp): per step min-sum decode "
+                    "+ error count of a resident batch on every GPU, one grouped all-reduce of the counters",
+            "value": tot["frames"] / el, "unit": "frames/s", "n_gpus": n, "devices": devices, "steps": steps, "warmup": warmup,
+            "ms_per_step": el / steps * 1e3, "frames_per_gpu_per_step": frames, "reduction": m.reduction,
+            "collective": "rccl ncclAllReduce 5 x uint64, one ncclGroupStart/End per step" if m.reduction == "rccl" else
+                          ("host sum of the five counters (shards share a device)" if n > 1 else None),
+            "comm_inits": int(m.lib.ldpc_hip_multi_comm_inits()),
+            "fer": tot["nde"] / tot["frames"], "mean_iters_per_frame": tot["sum_abs_iters"] / tot["frames"],
+        }
+
+
+def run_abi_multi_child(args, timeout=900):
+    """the abi_multi leg in a fresh child process (this one may hold a torch.distributed rank's GPU state, or -- the launcher --
+    must never touch the GPU); returns its JSON or {"error": ...}"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                                                           "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", "abi_multi", "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--frames", str(args.frames)]
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"error": f"abi_multi leg exited with {p.returncode}", "stdout_tail": p.stdout[-500:]}
+        return json.loads(lines[-1])
+    except Exception as ex:
+        return {"error": repr(ex)}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher: this process -- which never touches the GPU -- starts the N ranks as fresh child
+    processes (one per GPU, torch.distributed rendezvous on 127.0.0.1), relays rank 0's JSON line with the abi_multi leg (a further
+    fresh child, after the ranks are gone) added, and exits non-zero if any rank fails."""
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--frames", str(args.frames), "--backend", args.backend, "--spawned", "--no-cpu-baseline"]
+    if args.no_extras:
+        cmd.append("--no-extras")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    deadline = time.time() + float(os.environ.get("LDPC_BENCH_RANK_TIMEOUT", "1500"))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs[1:]):
+        for r, p in enumerate(procs[1:], 1):
+            if p.poll() not in (None, 0):
+                failed = f"rank {r} exited with {p.returncode}"
+        if time.time() > deadline:
+            failed = "timeout"
+        if procs[0].poll() not in (None, 0):
+            failed = f"rank 0 exited with {procs[0].returncode}"
+        time.sleep(0.2)
+    out0 = ""
+    if failed is None:
+        try:
+            out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+            if procs[0].returncode != 0:
+                failed = f"rank 0 exited with {procs[0].returncode}"
+        except subprocess.TimeoutExpired:
+            failed = "timeout"
+    if failed is not None:
+        for p in procs:   # exactly the processes started above
+            if p.poll() is None:
+                p.kill()
+        print(f"bench.py: {failed}", file=sys.stderr)
+        return 1
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if not lines:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    out = json.loads(lines[-1])
+    out["launcher"] = "bench.py (parent process without GPU state started one fresh process per rank)"
+    out["abi_multi"] = run_abi_multi_child(args)
+    print(json.dumps(out))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,7 +389,15 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI, the measured configuration); gloo only rehearses the N>1 code path on a box "
                          "with fewer GPUs than ranks (ranks then share devices and the counters are reduced on the host)")
+    ap.add_argument("--leg", default=None, choices=["abi_multi"], help="internal: run only the C-ABI multi-device leg and print its JSON")
+    ap.add_argument("--spawned", action="store_true", help="internal: this rank was started by bench.py itself (the parent adds the abi_multi leg)")
     args = ap.parse_args()
+
+    if args.leg == "abi_multi":
+        print(json.dumps(abi_multi_leg(args.gpus, args.steps, args.warmup, args.frames)))
+        return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -278,9 +420,10 @@ def main():
     import ldpc_lib_amd
 
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.exit(f"bench.py rank {rank}/{world}: no GPU visible -- the decoder has no CPU fallback")
     if args.backend == "nccl" and world > ndev:
         sys.exit(f"{world} ranks but {ndev} GPUs: one rank per GPU is required with RCCL")
     local = local % max(ndev, 1)
@@ -430,8 +573,19 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
+    if rank != 0:
+        return
+    if world == 1 and not args.no_extras:
+        try:    # one shard, no communicator: the same entry point the N > 1 leg times
+            out["abi_multi"] = abi_multi_leg(1, max(3, min(args.steps, 10)), 1, B)
+        except Exception as ex:
+            out["abi_multi"] = {"error": repr(ex)}
+    elif world > 1 and not args.spawned:
+        # started by an external launcher: the other ranks are on their way out; a fresh child process (never this one re-executed)
+        # opens all N GPUs behind the C-ABI
+        torch.cuda.empty_cache()
+        out["abi_multi"] = run_abi_multi_child(args)
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

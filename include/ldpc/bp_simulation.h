@@ -177,9 +177,9 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
     if (devices.empty()) Env::fail("bp_simulation: empty device list");
     // a code search calls this once per candidate matrix (main_good_code_search.cpp:320): never wait for hiprtc here, start on the
     // table-driven / shape-unlimited kernel and move to the code-specialised instance when the background compile delivers it
-    const int jit_before = ldpc_hip_set_jit_mode(2);
+    const int jit_before = ldpc_hip_set_jit_mode_thread(2);   // this thread's opens only: concurrent callers keep their own mode
     const int open_rc = ldpc_hip_open_multi(decoder_type, b, c, M, hd.data(), devices.data(), (int)devices.size(), &ctx);  // :353-355
-    if (jit_before >= 0) (void)ldpc_hip_set_jit_mode(jit_before);
+    (void)ldpc_hip_set_jit_mode_thread(jit_before);
     if (open_rc != 0) Env::fail(ldpc_hip_last_error());
     max_batch *= (long long)devices.size();
 
@@ -232,7 +232,7 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
             const long long room = (long long)n_experiments + 1 - experiment;
             const long long B = batch < room ? batch : room;
             info.resize((size_t)B); iters.resize((size_t)B);
-            if (ldpc_hip_mt_get_state_multi(ctx, mt_words, &mt_pos) != 0) Env::fail(ldpc_hip_last_error());   // snapshot
+            if (ldpc_hip_mt_get_state_multi(ctx, mt_words, &mt_pos) != 0) Env::fail(ldpc_hip_last_error());   // snapshot (+ the frame count: experiment)
             if (ldpc_hip_mt_frames_multi(ctx, snr, modulation_type, punctured_blocks, max_iterations, 0.8 /*MS_ALPHA*/, B, info.data(),
                                          iters.data()) != 0)
                 Env::fail(ldpc_hip_last_error());
@@ -253,6 +253,7 @@ std::pair<double, double> bp_simulation_t(int q_mod, Mat const &H, int tailbite_
             }
             if (used < B) {  // stopped inside the batch: put the generator where the frame-by-frame loop leaves it
                 if (ldpc_hip_mt_set_state_multi(ctx, mt_words, mt_pos) != 0) Env::fail(ldpc_hip_last_error());
+                if (ldpc_hip_mt_set_frame_index_multi(ctx, experiment - used) != 0) Env::fail(ldpc_hip_last_error());   // set_state restarts the count
                 if (ldpc_hip_mt_advance_multi(ctx, snr, modulation_type, punctured_blocks, used) != 0) Env::fail(ldpc_hip_last_error());
             }
             if (batch < cap) batch = batch * 4 < cap ? batch * 4 : cap;
@@ -342,9 +343,9 @@ std::pair<double, double> bp_simulation_throughput_t(int q_mod, Mat const &H, in
     std::vector<int16_t> hd((size_t)b * c);
     for (int i = 0; i < b; ++i) for (int j = 0; j < c; ++j) hd[(size_t)i * c + j] = (int16_t)H(i, j);
     ldpc_hip_multi *m = nullptr;
-    const int jit_before = ldpc_hip_set_jit_mode(2);   // as in exact-replay mode: no waiting for hiprtc
+    const int jit_before = ldpc_hip_set_jit_mode_thread(2);   // as in exact-replay mode: no waiting for hiprtc
     const int open_rc = ldpc_hip_open_multi(decoder_type, b, c, M, hd.data(), devices.data(), (int)devices.size(), &m);
-    if (jit_before >= 0) (void)ldpc_hip_set_jit_mode(jit_before);
+    (void)ldpc_hip_set_jit_mode_thread(jit_before);
     if (open_rc != 0) Env::fail(ldpc_hip_last_error());
     if (ldpc_hip_multi_set_interleaver(m, permutation_type, permutation_block, permutation_inter) != 0) Env::fail(ldpc_hip_last_error());
     if (ncw > 0 && codewords && ldpc_hip_multi_set_codewords(m, codewords, ncw) != 0) Env::fail(ldpc_hip_last_error());

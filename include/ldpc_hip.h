@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDPC_HIP_ABI_VERSION 3
+#define LDPC_HIP_ABI_VERSION 4
 
 /* decoders.h:16-28 enum DEC_ID (only the binary decoders on the hot path are built) */
 #define LDPC_HIP_BP_DEC 0  /* bp_decod_qc_lm         decoders.cpp:1708 (Gallager BP, log domain) */
@@ -70,6 +70,9 @@ const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *ctx);
  * main_good_code_search.cpp:320 calls bp_simulation once per candidate matrix); ldpc::bp_simulation_t selects it.
  * Returns the previous mode, or LDPC_HIP_EINVAL. */
 int ldpc_hip_set_jit_mode(int mode);
+/* The same choice for the CALLING THREAD only (-1 = no override; the environment variable still wins).  Returns the thread's previous
+ * override.  The C++ harnesses use this around their ldpc_hip_open_multi so that concurrent callers do not see each other's mode. */
+int ldpc_hip_set_jit_mode_thread(int mode);
 /* Name of the kernel the last ldpc_hip_decode_dev call on this context launched.  It differs from ldpc_hip_kernel_name only
  * for IMS_DEC with parameters beyond int8 (MS_DBITS > 8, MS_QBITS > 8 or alpha > 1), which run on the table-driven int32 kernel. */
 const char *ldpc_hip_last_launch(const ldpc_hip_ctx *ctx);
@@ -226,6 +229,10 @@ int ldpc_hip_mt_jump_host(const uint32_t state_in[624], int log2_words, uint32_t
  * count (which of the ldpc_hip_set_codewords codewords a frame carries: frame f -> codeword f % ncw). */
 int ldpc_hip_mt_set_state(ldpc_hip_ctx *ctx, const uint32_t state[624], int pos);
 int ldpc_hip_mt_get_state(ldpc_hip_ctx *ctx, uint32_t state[624], int *pos);
+/* The frame count that belongs to a snapshot: a caller that rolls the generator back with ldpc_hip_mt_set_state (the harness after an
+ * early stop, bp_simulation.cpp:820) and keeps drawing restores it too, so that frame f of the run still carries codeword f % ncw. */
+long long ldpc_hip_mt_get_frame_index(const ldpc_hip_ctx *ctx);
+int ldpc_hip_mt_set_frame_index(ldpc_hip_ctx *ctx, long long frames_taken);
 /* The next `count` values of next_random_gaussian() (commons_portable.cpp:174-178) to d_out [count] (device; NULL = draw and drop). */
 int ldpc_hip_mt_normal_dev(ldpc_hip_ctx *ctx, long long count, double *d_out, void *stream);
 /* Same into a HOST array (convenience; the harness uses it to check once per process that the device stream reproduces THIS host's
@@ -257,7 +264,13 @@ int ldpc_hip_open_multi(int decoder_id, int rh, int nh, int M, const int16_t *hd
 void ldpc_hip_close_multi(ldpc_hip_multi *m);
 int ldpc_hip_multi_shards(const ldpc_hip_multi *m);
 ldpc_hip_ctx *ldpc_hip_multi_ctx(ldpc_hip_multi *m, int shard);      /* per-shard settings (ims params, bp chain, profiling) */
+void *ldpc_hip_multi_stream(ldpc_hip_multi *m, int shard);          /* the shard's hipStream_t (work of the *_multi calls runs on it) */
 const char *ldpc_hip_multi_reduction(const ldpc_hip_multi *m);      /* "rccl" or "host" */
+/* Communicators are made once per device list and process (ncclCommInitAll is far more expensive than a short bp_simulation call,
+ * and a code search opens a multi context per candidate matrix: main_good_code_search.cpp:320); ldpc_hip_close_multi hands them back to
+ * the cache.  comm_inits = ncclCommInitAll calls so far; release_comms destroys the sets no open multi context holds. */
+long long ldpc_hip_multi_comm_inits(void);
+void ldpc_hip_multi_release_comms(void);
 int ldpc_hip_multi_set_interleaver(ldpc_hip_multi *m, int permutation_type, int permutation_block, int permutation_inter);
 int ldpc_hip_multi_set_codewords(ldpc_hip_multi *m, const uint8_t *codewords, int ncw);
 int ldpc_hip_multi_set_random_codewords(ldpc_hip_multi *m, uint64_t seed, int ncw);
@@ -269,6 +282,12 @@ int ldpc_hip_simulate_multi(ldpc_hip_multi *m, double snr_db, int modulation_typ
 int ldpc_hip_frames_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha,
                           uint64_t seed, long long first_frame, long long B, long long batch, int32_t *frame_info, int32_t *iters,
                           unsigned long long counters[4], unsigned long long *sum_abs_iters);
+/* The hot path on batches already RESIDENT on the GPUs (what bench.py times at N > 1): shard i decodes d_llr[i] ([B_per_shard][N]
+ * float64 on devices[i]) on its own stream and counts the errors -- its frames are global frames first_frame + i*B_per_shard + f for the
+ * codeword choice --, then one all-reduce of the five counters.  d_llr: HOST array of n device pointers.  Synchronous.  If any shard
+ * fails before the all-reduce, no shard enters it and the call returns that shard's error (bp_simulation.cpp:716-759 per frame). */
+int ldpc_hip_decode_count_multi(ldpc_hip_multi *m, const double *const *d_llr, long long B_per_shard, long long first_frame, int maxiter,
+                                double alpha, unsigned long long counters[4], unsigned long long *sum_abs_iters);
 /* ldpc_hip_decode_host over the shards: contiguous slices of the batch, one host thread per shard (BP_DEC with the frame chain
  * on is sequential by definition and runs on shard 0). */
 int ldpc_hip_decode_host_multi(ldpc_hip_multi *m, double *llr, long long B, int maxiter, int decision, double alpha, double *decword,
@@ -278,6 +297,7 @@ int ldpc_hip_decode_host_multi(ldpc_hip_multi *m, double *llr, long long B, int 
  * back in frame order.  advance = draw and drop B frames on every shard (roll-forward after an early stop). */
 int ldpc_hip_mt_set_state_multi(ldpc_hip_multi *m, const uint32_t state[624], int pos);
 int ldpc_hip_mt_get_state_multi(ldpc_hip_multi *m, uint32_t state[624], int *pos);
+int ldpc_hip_mt_set_frame_index_multi(ldpc_hip_multi *m, long long frames_taken);
 int ldpc_hip_mt_advance_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, long long B);
 int ldpc_hip_mt_frames_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha,
                              long long B, int32_t *frame_info, int32_t *iters);

@@ -127,7 +127,21 @@ def load_library():
     lib.ldpc_hip_mt_llr_dev.argtypes = [vp, f64, i32, i32, i64, vp, vp]
     lib.ldpc_hip_mt_frames.argtypes = [vp, f64, i32, i32, i32, f64, i64, vp, vp]
     lib.ldpc_hip_mt_frames_slice.argtypes = [vp, f64, i32, i32, i32, f64, i64, i64, i64, vp, vp]
-    if lib.ldpc_hip_abi_version() != 3:
+    lib.ldpc_hip_set_jit_mode_thread.argtypes = [i32]
+    lib.ldpc_hip_mt_set_frame_index.argtypes = [vp, i64]
+    lib.ldpc_hip_mt_get_frame_index.argtypes = [vp]
+    lib.ldpc_hip_mt_get_frame_index.restype = i64
+    lib.ldpc_hip_multi_stream.argtypes = [vp, i32]
+    lib.ldpc_hip_multi_stream.restype = vp
+    lib.ldpc_hip_multi_comm_inits.restype = i64
+    lib.ldpc_hip_multi_release_comms.restype = None
+    lib.ldpc_hip_decode_count_multi.argtypes = [vp, vp, i64, i64, i32, f64, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.ldpc_hip_mt_set_state_multi.argtypes = [vp, vp, i32]
+    lib.ldpc_hip_mt_get_state_multi.argtypes = [vp, vp, C.POINTER(i32)]
+    lib.ldpc_hip_mt_set_frame_index_multi.argtypes = [vp, i64]
+    lib.ldpc_hip_mt_advance_multi.argtypes = [vp, f64, i32, i32, i64]
+    lib.ldpc_hip_mt_frames_multi.argtypes = [vp, f64, i32, i32, i32, f64, i64, vp, vp]
+    if lib.ldpc_hip_abi_version() != 4:
         raise LdpcHipError("libldpc_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -294,6 +308,13 @@ class LdpcHip:
         _check(self.lib, self.lib.ldpc_hip_mt_get_state(self.h, st.ctypes.data, C.byref(pos)), "ldpc_hip_mt_get_state")
         return st, pos.value
 
+    def mt_frame_index(self):
+        """Frames drawn since mt_set_state (which codeword a frame carries: f % ncw); part of a generator snapshot."""
+        return int(self.lib.ldpc_hip_mt_get_frame_index(self.h))
+
+    def mt_set_frame_index(self, frames_taken):
+        _check(self.lib, self.lib.ldpc_hip_mt_set_frame_index(self.h, int(frames_taken)), "ldpc_hip_mt_set_frame_index")
+
     def mt_normal(self, count, out=None, skip=False, stream=None):
         """The next `count` values of upstream's next_random_gaussian() (float64 CUDA tensor); skip=True draws and drops them."""
         import torch
@@ -419,6 +440,54 @@ class LdpcHipMulti:
         if records:
             out["frame_info"], out["iters"] = info, its
         return out
+
+    def ctx(self, shard):
+        """Raw handle of shard i's context (per-shard settings and the single-device entry points)."""
+        return C.c_void_p(self.lib.ldpc_hip_multi_ctx(self.h, int(shard)))
+
+    def stream(self, shard):
+        return C.c_void_p(self.lib.ldpc_hip_multi_stream(self.h, int(shard)))
+
+    def channel_llr(self, shard, out, snr_db, seed, first_frame, modulation=0, punctured_blocks=0, T=26.0):
+        """Fills `out` (float64 CUDA tensor [B, N] on the shard's device) with the decoder input of frames [first_frame, first_frame + B),
+        on the shard's stream."""
+        rc = self.lib.ldpc_hip_channel_llr_dev(self.ctx(shard), float(snr_db), int(modulation), int(punctured_blocks), float(T), int(seed),
+                                               int(first_frame), int(out.shape[0]), C.c_void_p(out.data_ptr()), self.stream(shard))
+        _check(self.lib, rc, "ldpc_hip_channel_llr_dev")
+        return out
+
+    def decode_count(self, batches, maxiter, first_frame=0, alpha=0.8):
+        """The hot path on batches resident on the GPUs: batches[i] = float64 CUDA tensor [B, N] on shard i's device.  Returns the
+        all-reduced counters."""
+        assert len(batches) == self.shards
+        B = int(batches[0].shape[0])
+        ptrs = (C.c_void_p * self.shards)(*[C.c_void_p(b.data_ptr()) for b in batches])
+        cnt = (C.c_ulonglong * 4)()
+        sit = C.c_ulonglong()
+        rc = self.lib.ldpc_hip_decode_count_multi(self.h, ptrs, B, int(first_frame), int(maxiter), float(alpha), cnt, C.byref(sit))
+        _check(self.lib, rc, "ldpc_hip_decode_count_multi")
+        return {"nse": cnt[0], "nde": cnt[1], "nue": cnt[2], "frames": cnt[3], "sum_abs_iters": sit.value}
+
+    def mt_set_state(self, state, pos):
+        st = np.ascontiguousarray(state, dtype=np.uint32)
+        _check(self.lib, self.lib.ldpc_hip_mt_set_state_multi(self.h, st.ctypes.data, int(pos)), "ldpc_hip_mt_set_state_multi")
+
+    def mt_get_state(self):
+        st = np.empty(624, dtype=np.uint32)
+        pos = C.c_int()
+        _check(self.lib, self.lib.ldpc_hip_mt_get_state_multi(self.h, st.ctypes.data, C.byref(pos)), "ldpc_hip_mt_get_state_multi")
+        return st, pos.value
+
+    def mt_frames(self, snr_db, maxiter, B, modulation=0, punctured_blocks=0, alpha=0.8):
+        info = np.empty(int(B), dtype=np.int32)
+        its = np.empty(int(B), dtype=np.int32)
+        rc = self.lib.ldpc_hip_mt_frames_multi(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(maxiter), float(alpha), int(B),
+                                               info.ctypes.data, its.ctypes.data)
+        _check(self.lib, rc, "ldpc_hip_mt_frames_multi")
+        return info, its
+
+    def mt_advance(self, snr_db, B, modulation=0, punctured_blocks=0):
+        _check(self.lib, self.lib.ldpc_hip_mt_advance_multi(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(B)), "ldpc_hip_mt_advance_multi")
 
     def decode_host(self, llr, maxiter, decision=0, alpha=0.8, clobber_sp_input=True):
         llr = np.array(llr, dtype=np.float64, order="C", copy=True)

@@ -251,6 +251,7 @@ struct ldpc_hip_ctx {
 namespace {
 
 std::atomic<int> g_jit_mode{1};   // ldpc_hip_set_jit_mode: 0 never, 1 compile inside ldpc_hip_open, 2 compile in the background
+thread_local int t_jit_mode = -1;  // ldpc_hip_set_jit_mode_thread: this thread's override (-1 none)
 
 int jit_mode_effective() {
     if (const char *e = getenv("LDPC_HIP_JIT")) {   // the environment wins
@@ -259,6 +260,7 @@ int jit_mode_effective() {
         if (v == "sync") return 1;
         return atoi(e) != 0 ? 1 : 0;
     }
+    if (t_jit_mode >= 0) return t_jit_mode;
     return g_jit_mode.load();
 }
 
@@ -612,6 +614,12 @@ const char *ldpc_hip_kernel_name(const ldpc_hip_ctx *c) {
 int ldpc_hip_set_jit_mode(int mode) {
     if (mode < 0 || mode > 2) return fail(LDPC_HIP_EINVAL, "ldpc_hip_set_jit_mode: 0 (never), 1 (inside ldpc_hip_open) or 2 (in the background)");
     return g_jit_mode.exchange(mode);
+}
+int ldpc_hip_set_jit_mode_thread(int mode) {
+    if (mode < -1 || mode > 2) return fail(LDPC_HIP_EINVAL, "ldpc_hip_set_jit_mode_thread: -1 (no override), 0, 1 or 2");
+    const int before = t_jit_mode;
+    t_jit_mode = mode;
+    return before;
 }
 const char *ldpc_hip_last_launch(const ldpc_hip_ctx *c) { return c ? c->last_launch : ""; }
 

@@ -145,6 +145,7 @@ int mt_frames_slice(ldpc_hip_ctx *c, double snr_db, int modulation_type, int pun
     long long chunk_max = ((long long)8 << 30) / ((long long)sizeof(double) * c->N);
     chunk_max = chunk_max > (1 << 16) ? (1 << 16) : (chunk_max < 1 ? 1 : chunk_max);
     const long long first = m.frames_taken;
+    HIP_TRY(hipMemsetAsync(c->w_counters, 0, sizeof(unsigned long long) * 8, st));   // the count kernel accumulates; nobody reads the sum here
     for (long long c0 = 0; c0 < B; c0 += chunk_max) {
         const long long c1 = c0 + chunk_max < B ? c0 + chunk_max : B;
         const long long r_lo = lo > c0 ? lo : c0, r_hi = hi < c1 ? hi : c1, rows = r_hi > r_lo ? r_hi - r_lo : 0;
@@ -197,6 +198,14 @@ int ldpc_hip_mt_get_state(ldpc_hip_ctx *c, uint32_t state[624], int *pos) {
     *pos = c->mt.pos;
     return 0;
 }
+
+int ldpc_hip_mt_set_frame_index(ldpc_hip_ctx *c, long long frames_taken) {
+    if (!c || frames_taken < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_set_frame_index: bad argument");
+    c->mt.frames_taken = frames_taken;
+    return 0;
+}
+
+long long ldpc_hip_mt_get_frame_index(const ldpc_hip_ctx *c) { return c ? c->mt.frames_taken : -1; }
 
 int ldpc_hip_mt_normal_dev(ldpc_hip_ctx *c, long long count, double *d_out, void *stream_) {
     if (!c || count < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_normal_dev: bad argument");

@@ -116,12 +116,15 @@ class MtFrameSource:
         self.dec.mt_set_state(*mt19937_state(seed, (H.shape[1] - H.shape[0]) * tailbite_length))
 
     def snapshot(self):
-        return self.dec.mt_get_state()
+        """(624 words, next index, frames drawn so far): the frame count is part of the snapshot (codeword f % ncw of frame f)"""
+        st, pos = self.dec.mt_get_state()
+        return st, pos, self.dec.mt_frame_index()
 
     def restore_and_skip(self, snap, frames):
         """the generator where a frame-by-frame loop that stopped after `frames` frames of the round would have left it"""
         snr, mod, punct, _, _ = self.args
-        self.dec.mt_set_state(*snap)
+        self.dec.mt_set_state(snap[0], snap[1])
+        self.dec.mt_set_frame_index(snap[2])
         if frames:
             self.dec.mt_llr(snr, frames, modulation=mod, punctured_blocks=punct, skip=True)
 
@@ -183,7 +186,8 @@ def bp_simulation(H, tailbite_length, max_iterations, n_frame_errors, n_experime
                 src.restore_and_skip(snap, used)      # stopped inside the round
             base += world * B
         if exact:
-            state["generator"] = src.snapshot()       # (624 words, next index): what upstream's `generator` holds afterwards
+            snap = src.snapshot()                     # (624 words, next index): what upstream's `generator` holds afterwards
+            state["generator"] = snap[:2] if isinstance(snap, tuple) else snap
     finally:
         if source is None:
             src.close()

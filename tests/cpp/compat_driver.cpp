@@ -8,7 +8,11 @@
 #include <cstring>
 #include <vector>
 
+#ifdef LDPC_COMPAT_UPSTREAM_HEADERS
+#include "decoders.h"       // UPSTREAM'S header and DEC_STATE layout (oracle/Makefile `ref`: _ref/compat_driver_upstream)
+#else
 #include "ldpc/decoders.h"
+#endif
 
 int main(int argc, char **argv) {
     if (argc < 3) return 2;
@@ -47,7 +51,8 @@ int main(int argc, char **argv) {
         memcpy(&dec[(size_t)b * N], st->decword, sizeof(double) * N);
         memcpy(&after[(size_t)b * N], st->y, sizeof(double) * N);
     }
-    // the batched extension must agree with the per-frame calls
+#ifndef LDPC_COMPAT_UPSTREAM_HEADERS
+    // the batched extension (not part of upstream's header) must agree with the per-frame calls
     std::vector<double> llr2 = llr, dec2((size_t)B * N);
     std::vector<int> it2(B);
     if (dec_id == BP_DEC) {   // BP carries the last frame's syndrome in the state (decoders.cpp:1742-1762): start over like the loop above did
@@ -60,6 +65,7 @@ int main(int argc, char **argv) {
     ldpc_decod_batch(st, llr2.data(), dec2.data(), it2.data(), B, maxiter, decision);
     if (memcmp(it2.data(), iters.data(), sizeof(int) * B) != 0) return 20;
     if (dec_id != BP_DEC && dec_id != SP_DEC && dec_id != TASP_DEC && dec_id != ASP_DEC && memcmp(dec2.data(), dec.data(), sizeof(double) * dec.size()) != 0) return 21;
+#endif
     decod_close(st);
 
     f = fopen(argv[2], "wb");

@@ -529,23 +529,31 @@ def test_upstream_bp_simulation_symbol_runs_on_the_gpu(L, case):
         assert (res.nde, res.experiment) == (170, 4001) and float.fromhex(got["FER"]) == 170 / 4001
     if dec_id == TASP_DEC:
         assert (res.nde, res.experiment) == (50, 821)
-    # the decoders.h call made through upstream's DEC_STATE layout: same frame through the C-ABI
+    # (the decoders.h surface under upstream's DEC_STATE layout is compared with the golden vectors, decoder by decoder, in
+    # test_decoders_h_call_surface[upstream_header]; here only: the call works in the same process as the harness)
     assert int(got["MS_ITERS"]) != 0 and 0 <= int(got["MS_ONES"]) <= 32 * M
 
 
+@pytest.mark.parametrize("layout", ["own_header", "upstream_header"])
 @pytest.mark.parametrize("name", ["ms_m64_1p2", "lms_m64_0p8", "sp_m64_2p0", "ms_m126_1p7", "ms_m1_4p0", "ims_m64_2p0", "tasp_m126_1p7",
                                   "asp_m64_1p2", "bp_m64_1p0_stale"])
-def test_decoders_h_call_surface(L, tmp_path, name):
-    """decod_open / hd fill / decod_init / <decoder>(st, st->y, st->decword, ...) / decod_close from a C++ program built
-    against include/ldpc/decoders.h, on the reference's golden vectors."""
+def test_decoders_h_call_surface(L, tmp_path, name, layout):
+    """decod_open / hd fill / decod_init / <decoder>(st, st->y, st->decword, ...) / decod_close from a C++ program, on the reference's
+    golden vectors (return values, decword as hard bits and as soft values, what is left in y) -- built against include/ldpc/decoders.h
+    ("own_header") and against UPSTREAM'S OWN decoders.h with its DEC_STATE layout ("upstream_header": oracle/_ref/compat_driver_upstream,
+    csrc/compat/decoders_compat.cpp with -DLDPC_COMPAT_UPSTREAM_HEADERS -- the flavour a maintainer links)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    _compat_lib(L)
-    exe = str(tmp_path / "compat_driver")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
-                           os.path.join(root, "tests", "cpp", "compat_driver.cpp"), "-o", exe,
-                           "-L", os.path.join(root, "ldpc-lib_amd"), "-lldpc_compat", "-lldpc_hip",
-                           "-Wl,-rpath," + os.path.join(root, "ldpc-lib_amd")])
+    if layout == "upstream_header":
+        exe = os.path.join(root, "oracle", "_ref", "compat_driver_upstream")
+        assert os.path.exists(exe), "oracle/_ref/compat_driver_upstream missing: run `make -C oracle ref` where /root/reference is mounted"
+    else:
+        _compat_lib(L)
+        exe = str(tmp_path / "compat_driver")
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                               os.path.join(root, "tests", "cpp", "compat_driver.cpp"), "-o", exe,
+                               "-L", os.path.join(root, "ldpc-lib_amd"), "-lldpc_compat", "-lldpc_hip",
+                               "-Wl,-rpath," + os.path.join(root, "ldpc-lib_amd")])
     g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     H, M, dec_id, maxiter = g["H"], int(g["M"]), int(g["dec_id"]), int(g["maxiter"])
     for decision, nfr in ((0, g["llr"].shape[0]), (1, g["soft"].shape[0])):
@@ -876,6 +884,38 @@ def test_background_specialisation_changes_tier_in_flight(L, torch, tmp_path, mo
     del t_open, t_jit
     with L.LdpcHip(dec_id, H, 64) as dec:
         assert "hiprtc" in dec.kernel_name                            # process cache
+
+
+def test_process_may_exit_while_a_background_compile_is_in_flight(L, tmp_path):
+    """Regression (round 2, gpurun_out/s7: SIGSEGV at exit): a process that ends while the hiprtc worker still compiles must leave
+    with its own exit code -- the worker's exit handler waits for the compile in flight while hiprtc's compiler is still alive.
+    Three fresh processes: one exits right after ldpc_hip_open, one after a decode on the first tier, one leaves the context open."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch
+import ldpc_lib_amd as L
+from ldpc_testlib import load_base_matrix, relift, awgn_llr, TASP_DEC, MS_DEC
+mode = sys.argv[1]
+H = relift(load_base_matrix(), 64).copy()
+H[H > 0] = (H[H > 0] * 7 + 3 + len(mode)) % 64
+dec = L.LdpcHip(TASP_DEC if mode == "decode" else MS_DEC, H, 64)
+assert "hiprtc" not in dec.kernel_name, dec.kernel_name      # the instance is still being compiled
+if mode == "decode":
+    dec.decode(torch.from_numpy(awgn_llr(H, 64, 2.0, 1, 16)).cuda(), 15)
+    torch.cuda.synchronize()
+if mode != "leak":
+    dec.close()
+print("leaving", mode, flush=True)
+sys.exit(7)
+"""
+    for mode in ("open", "decode", "leak"):
+        env = dict(os.environ, LDPC_HIP_JIT="async", LDPC_HIP_CACHE_DIR=str(tmp_path / mode))
+        p = subprocess.run([sys.executable, "-c", script.format(root=root), mode], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 7 and "leaving " + mode in p.stdout, (mode, p.returncode, p.stdout[-500:], p.stderr[-1500:])
 
 
 def test_contexts_closed_before_their_compile_are_dropped(L, torch, tmp_path, monkeypatch):

@@ -151,3 +151,90 @@ def test_global_tier_on_the_compiled_references_vectors(L, torch, name, monkeypa
             assert np.array_equal((soft.cpu().numpy() > 0.5).astype(np.float64), g["soft"])
         else:
             assert np.array_equal(soft.cpu().numpy(), g["soft"])
+
+
+# ---- a bounded slice of tools/soak.py inside the suite (the random-protograph evidence was builder-run only) ------------
+def _soak_case(rng, big):
+    rh = int(rng.randint(2, 30 if big else 13))
+    nh = rh + int(rng.randint(2, 30 if big else 14))
+    M = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 21, 27, 32, 33, 40, 47, 48, 63, 64, 65, 67, 96, 100, 126, 128, 129, 160, 200, 256] + ([300, 513] if big else [])))
+    weights = tuple(int(x) for x in rng.randint(2, min(rh, 6) + 1, size=4))
+    return rh, nh, M, random_qc_code(rng, rh, nh, M, weights)
+
+
+def test_soak_slice_random_protographs_on_the_shape_unlimited_tier(L, torch, monkeypatch):
+    """Fixed seeds, <= 60 s: random protographs (2..29 block rows, liftings 1..513) x all seven decoders on the shape-unlimited tier
+    (no hiprtc, so the time goes into decoding) against the oracle -- hard bits, return values and soft values bit for bit."""
+    import time
+    monkeypatch.setenv("LDPC_HIP_FORCE_GLOBAL", "1")
+    rng = np.random.RandomState(20261005)
+    t0, done = time.time(), 0
+    for case in range(40):
+        if time.time() - t0 > 45 and done >= 42:
+            break
+        rh, nh, M, H = _soak_case(rng, True)
+        frames = 6 if M * nh > 20000 else 16 if M * nh > 2000 else 40
+        llr = np.concatenate([awgn_llr(H, M, s, 900 + case, frames // 2) for s in (2.0, 5.0)])
+        llr[0, :3] = [0.0, -0.0, 40000.0]
+        for dec_id in (MS_DEC, LMS_DEC, IMS_DEC, SP_DEC, TASP_DEC, ASP_DEC, BP_DEC):
+            if dec_id == ASP_DEC and ((H >= 0).sum(axis=0) == 2).all():
+                continue   # upstream's all-columns-of-weight-2 branch has its own test
+            name, _ = _check(L, torch, dec_id, H, M, llr, 30, expect_kernel="global")
+            done += 1
+    assert done >= 42, done
+
+
+def test_soak_slice_random_protographs_on_hiprtc_instances(L, torch, tmp_path, monkeypatch):
+    """The same against code-specialised instances compiled on the spot (hiprtc): five random codes x the three min-sum bodies, with
+    lifting classes that hit ms_small / ms_m64 / ms_chunk / ms_body."""
+    monkeypatch.setenv("LDPC_HIP_CACHE_DIR", str(tmp_path))
+    rng = np.random.RandomState(20261006)
+    done = 0
+    for case, M in enumerate((13, 64, 100, 27, 200)):
+        rh = int(rng.randint(3, 9))
+        nh = rh + int(rng.randint(3, 10))
+        H = random_qc_code(rng, rh, nh, M, tuple(int(x) for x in rng.randint(2, min(rh, 5) + 1, size=4)))
+        if (H >= 0).sum(axis=1).max() > 8:
+            continue
+        llr = np.concatenate([awgn_llr(H, M, s, 950 + case, 12) for s in (2.0, 5.0)])
+        llr[0, :3] = [0.0, -0.0, 40000.0]
+        for dec_id in (MS_DEC, LMS_DEC, IMS_DEC):
+            name, _ = _check(L, torch, dec_id, H, M, llr, 30)
+            assert "hiprtc" in name, name
+            done += 1
+    assert done >= 9
+
+
+def test_chain_changes_do_not_touch_the_shape_unlimited_tiers_workspace(L, torch, monkeypatch):
+    """Regression (round 2, 4209a7b): prepare_chain -- run whenever the modulation, the interleaver or the codewords of a context
+    change -- freed the shape-unlimited tier's message workspace and the next decode used the stale pointer.  Decode, change the
+    chain twice with allocations in between that would recycle a freed block, decode again: still the oracle's bits."""
+    monkeypatch.setenv("LDPC_HIP_FORCE_GLOBAL", "1")
+    M = 64
+    H = relift(load_base_matrix(), M)
+    llr = awgn_llr(H, M, 1.5, 77, 48)
+    x = torch.from_numpy(llr).cuda()
+    for dec_id in (BP_DEC, MS_DEC):
+        o = Oracle(H, M)
+        d_ref, it_ref, _ = o.decode(dec_id, llr, 20, 0)
+        with L.LdpcHip(dec_id, H, M) as dec:
+            assert "global" in dec.kernel_name
+            if dec_id == BP_DEC:
+                dec.set_bp_chain(True, True)
+            hard, iters, _ = dec.decode(x, 20)
+            assert np.array_equal(iters.cpu().numpy(), it_ref)
+            junk = []
+            for mod in (1, 0, 2):
+                dec.awgn_llr(2.0, 1, 0, 8, modulation=mod)                  # prepare_chain(mod)
+                junk.append(torch.full((1 << 20,), float("nan"), dtype=torch.float64, device="cuda"))
+            dec.set_codewords(np.zeros((2, dec.N), dtype=np.uint8))
+            dec.awgn_llr(2.0, 1, 0, 8)
+            junk.append(torch.full((1 << 22,), float("nan"), dtype=torch.float64, device="cuda"))
+            torch.cuda.synchronize()
+            if dec_id == BP_DEC:
+                dec.set_bp_chain(True, True)                                # same starting syndrome as the oracle's fresh state
+            hard, iters, _ = dec.decode(x, 20)
+            torch.cuda.synchronize()
+            assert np.array_equal(iters.cpu().numpy(), it_ref)
+            assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
+            del junk

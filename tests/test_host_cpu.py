@@ -26,7 +26,7 @@ def test_build_entry_point_and_abi_exports():
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), f"{n} declared in ldpc_hip.h but not exported"
-    assert lib.ldpc_hip_abi_version() == 3
+    assert lib.ldpc_hip_abi_version() == 4
 
 
 def test_generator_state_conversion(tmp_path):
@@ -244,6 +244,40 @@ def test_two_rank_gloo_exact_replay_matches_single_process():
     for o in outs:
         line = [ln for ln in o.splitlines() if ln.startswith("RESULT")][0]
         assert json.loads(line.split(" ", 2)[2]) == want
+
+
+def test_bench_starts_its_own_ranks_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` with no launcher: the parent starts one fresh process per rank itself (it used to exit
+    with "launch with torch.distributed.run").  Without a GPU every rank must refuse loudly -- there is no CPU fallback to time -- and
+    the parent must report it with a non-zero exit code instead of hanging.  (The run itself is tests/test_gpu_chain.py's.)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: test_gpu_chain.py runs the real thing")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "rank 0/2: no GPU" in p.stderr and "rank 1/2: no GPU" in p.stderr, p.stderr   # both ranks were started, with the right world
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]              # and no result line was made up
+
+
+def test_multi_gpu_test_programs_build(tmp_path):
+    """tests/cpp/multi_driver.c and the host-memory stand-in for librccl (tests/cpp/rccl_stub.cpp) that the GPU suite uses to drive the
+    N > 1 communicator code on a one-GPU box: they must build here, and the stand-in must export what csrc/ldpc_multi.hpp resolves."""
+    import ctypes
+    hipinc = ["-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include"]
+    stub = tmp_path / "librccl_stub.so"
+    subprocess.check_call(["g++", "-O1", "-Wall", "-fPIC", "-shared", *hipinc, os.path.join(ROOT, "tests", "cpp", "rccl_stub.cpp"), "-o", str(stub),
+                           "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", *hipinc, "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "multi_driver.c"),
+                           "-o", str(tmp_path / "multi_driver"), "-L", os.path.join(ROOT, "ldpc-lib_amd"), "-lldpc_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.join(ROOT, "ldpc-lib_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    lib = ctypes.CDLL(str(stub))
+    src = open(os.path.join(ROOT, "ldpc-lib_amd", "csrc", "ldpc_multi.hpp")).read()
+    wanted = re.findall(r"LDPC_RCCL_SYM\((\w+)\)", src.split("#define LDPC_RCCL_SYM")[1].split("#undef")[0])
+    assert len(wanted) >= 6
+    for w in wanted:
+        assert hasattr(lib, "nccl" + w), w
 
 
 def test_c_example_builds_against_the_header(tmp_path):
