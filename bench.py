@@ -154,11 +154,12 @@ def sources_hash():
     """Hash of the kernel sources: PMC figures in profiles/r02_pmc.json are only quoted for the code they were measured on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "ldpc-lib_amd", "csrc")
-    for fn in sorted(os.listdir(d)):
-        p = os.path.join(d, fn)
-        if os.path.isfile(p) and fn.endswith((".hpp", ".hip")):
-            h.update(fn.encode())
-            h.update(open(p, "rb").read())
+    for sub in ("", "aot"):
+        for fn in sorted(os.listdir(os.path.join(d, sub))):
+            p = os.path.join(d, sub, fn)
+            if os.path.isfile(p) and fn.endswith((".hpp", ".hip")):
+                h.update(fn.encode())
+                h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
 
 

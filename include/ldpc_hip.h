@@ -292,15 +292,21 @@ int ldpc_hip_decode_count_multi(ldpc_hip_multi *m, const double *const *d_llr, l
  * on is sequential by definition and runs on shard 0). */
 int ldpc_hip_decode_host_multi(ldpc_hip_multi *m, double *llr, long long B, int maxiter, int decision, double alpha, double *decword,
                                int32_t *iters, int clobber_sp_input);
-/* The exact-replay stream (ldpc_hip_mt_*) over the shards: every shard runs the same generator over the whole batch -- the stream
- * is sequential by nature and costs a fraction of the decode -- and decodes its contiguous slice of the B frames; the records come
- * back in frame order.  advance = draw and drop B frames on every shard (roll-forward after an early stop). */
+/* The exact-replay stream (ldpc_hip_mt_*) over the shards.  The generator's stream is sequential, but jump-ahead reaches any point of
+ * it: the round's word tape is cut at the expected positions of the shards' first items, every shard makes only the sub-streams around
+ * its own stretch (+- 8 standard deviations) and counts the accepted polar-method attempts in it, the n counts go through the host (a
+ * counters-only exchange), and every shard then emits and decodes its contiguous share of each round's frames; the records come back
+ * in frame order and all shards are left in the state the sequential loop would be in.  Per-shard generation work is ~1/n; if a
+ * margin is ever exceeded the round is redone with the whole tape on every shard (ldpc_hip_multi_mt_stats counts both kinds), so
+ * results never depend on the estimates.  LDPC_HIP_MT_SHARDED=0 forces the whole-tape mode, =1 shards even short rounds.
+ * advance = draw and drop B frames on every shard (roll-forward after an early stop). */
 int ldpc_hip_mt_set_state_multi(ldpc_hip_multi *m, const uint32_t state[624], int pos);
 int ldpc_hip_mt_get_state_multi(ldpc_hip_multi *m, uint32_t state[624], int *pos);
 int ldpc_hip_mt_set_frame_index_multi(ldpc_hip_multi *m, long long frames_taken);
 int ldpc_hip_mt_advance_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, long long B);
 int ldpc_hip_mt_frames_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha,
                              long long B, int32_t *frame_info, int32_t *iters);
+void ldpc_hip_multi_mt_stats(const ldpc_hip_multi *m, long long *sharded_rounds, long long *fallback_rounds);
 
 /* Timing aid for bench.py: average duration in milliseconds of the decode kernel launches recorded with
  * HIP events on their own stream since the last reset (events are only recorded while enabled). */

@@ -26,23 +26,46 @@ def library_path():
     return os.path.join(_PKG_DIR, _LIB_NAME)
 
 
-def build_library(force=False, verbose=False):
-    """Compile csrc/*.hip for gfx950 into ldpc-lib_amd/libldpc_hip.so (in-tree, so it travels with the repo snapshot).
+def build_library(force=False, verbose=False, jobs=None):
+    """Compile csrc/ldpc_hip.hip (host side, table-driven / shape-unlimited / front-end / generator kernels) and csrc/aot/*.hip (the
+    ahead-of-time code-specialised instances) for gfx950 -- one hipcc per translation unit, in parallel -- and link them into
+    ldpc-lib_amd/libldpc_hip.so (in-tree, so it travels with the repo snapshot).
     -ffp-contract=off is part of the numerics contract: `y + s*alpha` must stay two roundings (decoders.cpp:4682)."""
+    from concurrent.futures import ThreadPoolExecutor
     src_dir = os.path.join(_PKG_DIR, "csrc")
-    srcs = [os.path.join(src_dir, "ldpc_hip.hip")]
-    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if os.path.isfile(os.path.join(src_dir, f))]
-    deps += [os.path.join(_ROOT, "include", "ldpc_hip.h"), os.path.join(_ROOT, "include", "ldpc", "interleaver.h"),
-             os.path.join(_ROOT, "include", "ldpc", "encoder.h")]
-    out = library_path()
-    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
-        return out
+    aot_dir = os.path.join(src_dir, "aot")
+    srcs = [os.path.join(src_dir, "ldpc_hip.hip")] + sorted(os.path.join(aot_dir, f) for f in os.listdir(aot_dir) if f.endswith(".hip"))
+    headers = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith(".hpp")]
+    headers += [os.path.join(_ROOT, "include", "ldpc_hip.h"), os.path.join(_ROOT, "include", "ldpc", "interleaver.h"),
+                os.path.join(_ROOT, "include", "ldpc", "encoder.h")]
+    aot_headers = [os.path.join(src_dir, f) for f in ("ldpc_aot.hpp", "ldpc_spec.hpp", "code_appendix_c_m64.hpp")]
+    obj_dir = os.path.join(_PKG_DIR, "build")
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-I", os.path.join(_ROOT, "include"), *srcs, "-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I", os.path.join(_ROOT, "include")]
+
+    def newer(target, deps):
+        return os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps)
+
+    todo, objs = [], []
+    for src in srcs:
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        deps = [src] + (aot_headers if os.path.dirname(src) == aot_dir else headers)
+        if force or not newer(obj, deps):
+            todo.append([hipcc, *flags, "-c", src, "-o", obj])
+    out = library_path()
+    if not todo and newer(out, objs):
+        return out
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, todo))
+    run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", out])
     return out
 
 
@@ -141,6 +164,8 @@ def load_library():
     lib.ldpc_hip_mt_set_frame_index_multi.argtypes = [vp, i64]
     lib.ldpc_hip_mt_advance_multi.argtypes = [vp, f64, i32, i32, i64]
     lib.ldpc_hip_mt_frames_multi.argtypes = [vp, f64, i32, i32, i32, f64, i64, vp, vp]
+    lib.ldpc_hip_multi_mt_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    lib.ldpc_hip_multi_mt_stats.restype = None
     if lib.ldpc_hip_abi_version() != 4:
         raise LdpcHipError("libldpc_hip.so ABI version mismatch")
     _lib = lib
@@ -485,6 +510,15 @@ class LdpcHipMulti:
                                                info.ctypes.data, its.ctypes.data)
         _check(self.lib, rc, "ldpc_hip_mt_frames_multi")
         return info, its
+
+    def mt_stats(self):
+        """(generation rounds shared out over the shards, rounds redone with the whole tape on every shard)"""
+        a, b = C.c_longlong(), C.c_longlong()
+        self.lib.ldpc_hip_multi_mt_stats(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def mt_set_frame_index(self, frames_taken):
+        _check(self.lib, self.lib.ldpc_hip_mt_set_frame_index_multi(self.h, int(frames_taken)), "ldpc_hip_mt_set_frame_index_multi")
 
     def mt_advance(self, snr_db, B, modulation=0, punctured_blocks=0):
         _check(self.lib, self.lib.ldpc_hip_mt_advance_multi(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(B)), "ldpc_hip_mt_advance_multi")

@@ -1,0 +1,5 @@
+// aot/tasp.hip -- ahead-of-time instances (ldpc_aot.hpp), one translation unit of the parallel build
+#include "../ldpc_aot.hpp"
+
+LDPC_AOT_KERNEL(tasp_spec_appendix_c_m64_kernel, tasp_body, CodeAppendixCM64, 64, 1)
+LDPC_AOT_KERNEL(tasp_spec_appendix_c_m126_kernel, tasp_body, CodeAppendixCM126, 128, 1)

@@ -23,8 +23,7 @@
 #include "ldpc_kernels.hpp"
 #include "ldpc_global.hpp"
 #include "ldpc_ms_fast.hpp"
-#include "ldpc_spec.hpp"
-#include "code_appendix_c_m64.hpp"
+#include "ldpc_aot.hpp"   // ldpc_spec.hpp, code_appendix_c_m64.hpp + the declarations of the aot/*.hip kernels
 #include "ldpc_sumprod.hpp"
 #include "ldpc_mt.hpp"
 #include "ldpc_encode.hpp"
@@ -56,28 +55,8 @@ constexpr int kRWM = 16;   // max circulants per block row (edge-sign bits per r
 
 }  // namespace
 
-// ---- code-specialised instances (ldpc_spec.hpp) ------------------------------------------------------------------
-// Ahead of time: the shipped example code at the liftings the BASELINE configurations use.
-// Everything else is compiled at ldpc_hip_open() with hiprtc from the same header (ldpc_jit.hpp).
-#define LDPC_AOT_KERNEL(name, body, Code, threads, waves_per_simd)                                   \
-    __global__ void __launch_bounds__(threads, waves_per_simd) name(const ldpc_spec::SpecArgs a) {   \
-        ldpc_spec::body<ldpc_spec::Code>(a);                                                         \
-    }
-LDPC_AOT_KERNEL(ms_spec_appendix_c_m64_kernel, ms_m64_body, CodeAppendixCM64, 64, 2)
-LDPC_AOT_KERNEL(ms_spec_appendix_c_m126_kernel, ms_body, CodeAppendixCM126, 128, 2)
-LDPC_AOT_KERNEL(ms_chunk_appendix_c_m126_kernel, ms_chunk_body, CodeAppendixCM126, 64, 1)
-LDPC_AOT_KERNEL(ms_spec_appendix_c_m512_kernel, ms_body, CodeAppendixCM512, 512, 2)
-LDPC_AOT_KERNEL(ims_spec_appendix_c_m64_kernel, ims_body, CodeAppendixCM64, 64, 3)
-LDPC_AOT_KERNEL(ims_spec_appendix_c_m126_kernel, ims_body, CodeAppendixCM126, 128, 2)
-LDPC_AOT_KERNEL(lms_spec_appendix_c_m64_kernel, lms_body, CodeAppendixCM64, 64, 2)
-LDPC_AOT_KERNEL(lms_spec_appendix_c_m512_kernel, lms_body, CodeAppendixCM512, 512, 2)
-// asp / bp: two frames per CU (<= 128 VGPRs, some spills) beats one frame with 243 VGPRs; sp: four waves per frame (below)
-LDPC_AOT_KERNEL(sp_spec_appendix_c_m64_kernel, sp_body, CodeAppendixCM64, 256, 2)   // four waves per frame, two frames per CU (ldpc_spec::kSpBodyWaves)
-LDPC_AOT_KERNEL(bp_spec_appendix_c_m64_kernel, bp_body, CodeAppendixCM64, 512, 4)
-LDPC_AOT_KERNEL(asp_spec_appendix_c_m64_kernel, asp_body, CodeAppendixCM64, 512, 4)
-LDPC_AOT_KERNEL(tasp_spec_appendix_c_m64_kernel, tasp_body, CodeAppendixCM64, 64, 1)
-LDPC_AOT_KERNEL(tasp_spec_appendix_c_m126_kernel, tasp_body, CodeAppendixCM126, 128, 1)
-
+// ---- code-specialised instances (ldpc_spec.hpp): the ahead-of-time ones are defined in aot/*.hip and declared in ldpc_aot.hpp;
+// everything else is compiled at ldpc_hip_open() with hiprtc from the same header (ldpc_jit.hpp).
 namespace {
 
 // the opened base matrix as edge lists (row-major = upstream's j-then-k loop order)
@@ -203,6 +182,10 @@ struct ldpc_hip_ctx {
     std::shared_ptr<ldpc_jit::Job> jit_job;   // LDPC_HIP_JIT=async: the instance is being compiled in the background; until it is
     std::string jit_name;                     // ready the table-driven / shape-unlimited tier runs (identical bits)
     bool global_is_fallback = false;
+    // persistent launch of the one-wave-per-frame min-sum body (SpecArgs::queue)
+    unsigned *d_queue = nullptr;
+    int persist_grid = 0;     // resident waves of that kernel on this device (0: not determined yet)
+    bool persist_jit = false; // ... determined for the hiprtc instance (a context may move from one to the other)
     std::string kernel_name;  // what this context launches (ldpc_hip_kernel_name)
     std::string generic_name; // the table-driven kernel of this decoder, if one serves this code shape
     const char *last_launch = "";  // ldpc_hip_last_launch
@@ -586,6 +569,7 @@ void ldpc_hip_close(ldpc_hip_ctx *c) {
     if (c->d_col_slot) (void)hipFree(c->d_col_slot);
     if (c->d_edge_row) (void)hipFree(c->d_edge_row);
     if (c->w_counters) (void)hipFree(c->w_counters);
+    if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_ims_coef) (void)hipFree(c->d_ims_coef);
     if (c->d_bp_stale) (void)hipFree(c->d_bp_stale);
     if (c->d_bp_synd) (void)hipFree(c->d_bp_synd);
@@ -721,8 +705,28 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
         }
         sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
         sa.nframes = B;
+        // the flagship (M = 64 flooding min-sum, one frame per wave): persistent waves that pull frames from a queue
+        static const bool persist_on = !(getenv("LDPC_HIP_PERSISTENT") && atoi(getenv("LDPC_HIP_PERSISTENT")) == 0);
+        const bool persistent = persist_on && c->decoder_id == LDPC_HIP_MS_DEC && c->M == 64 && c->spec_threads == 64 && c->spec_frames_per_block == 1;
+        if (persistent) {
+            if (!c->d_queue) HIP_TRY(hipMalloc(&c->d_queue, 64));
+            if (c->persist_grid == 0 || c->persist_jit != (c->spec_aot == nullptr)) {   // resident waves: occupancy x CUs (8 x 256 on an MI355X)
+                int per_cu = 0, cus = 0;
+                hipError_t e = c->spec_aot ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, c->spec_aot, 64, c->spec_lds)
+                                           : hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, c->spec_jit->fn, 64, c->spec_lds);
+                if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 8; }
+                HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+                c->persist_grid = per_cu * (cus > 0 ? cus : 256);
+                c->persist_jit = c->spec_aot == nullptr;
+            }
+        }
         auto launch = [&](long long frames) -> int {
-            const long long blocks = (frames + c->spec_frames_per_block - 1) / c->spec_frames_per_block;
+            long long blocks = (frames + c->spec_frames_per_block - 1) / c->spec_frames_per_block;
+            if (persistent && blocks > c->persist_grid) {
+                HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned), stream));
+                sa.queue = c->d_queue;
+                blocks = c->persist_grid;
+            }
             void *kargs[] = {&sa};
             if (c->spec_aot) {
                 if (int rc = set_lds_limit(c->spec_aot, c->spec_lds)) return rc;

@@ -251,11 +251,12 @@ __global__ void __launch_bounds__(640) mt_jump_kernel(const JumpArgs a) {
 
 // ---- device: one wavefront per stream ---------------------------------------------------------------------------------------
 struct GenArgs {
-    const uint32_t *states;   // [S][624]
-    uint32_t *xraw;           // [624 + S * stride] untempered words; stream j writes [624 + j*stride, 624 + (j+1)*stride)
-    int S;
+    const uint32_t *states;   // [S][624] start states of the window's streams
+    uint32_t *xraw;           // the window: xraw[0] = tape word first * stride; stream j (of the window) writes [624 + j*stride, 624 + (j+1)*stride)
+    int S;                    // streams in the window
+    long long first;          // tape index of the window's first stream
     int log2_stride;          // 18 .. 20
-    long long words;          // words wanted behind the first 624 (a multiple of 64): the last stream stops there
+    long long words;          // tape words wanted behind the first 624 (a multiple of 64): streams stop there
 };
 
 // Wave-level ordering point for LDS traffic between lanes of ONE wave: the LDS executes a wave's operations in issue order, so only
@@ -286,7 +287,7 @@ __device__ __forceinline__ void mt_group(uint32_t *x, uint32_t *out_blk, const i
         if (lo + 64 <= MTN || lane < MTN - lo) {
             const uint32_t v = mt_next(x0[u], x1[u], xm[u]);
             x[i] = v;
-            if ((uint32_t)lo < remaining) out_blk[i] = v;   // uniform: the stream ends on a multiple of 64 words into its last block
+            if ((uint32_t)i < remaining) out_blk[i] = v;   // per lane: a stream may end anywhere inside its last block (624 = 9 * 64 + 48)
         }
     }
     mt_wave_sync();
@@ -299,17 +300,16 @@ __global__ void __launch_bounds__(256) mt_generate_kernel(const GenArgs a) {
     if (j >= a.S) return;    // no workgroup barrier below: a wave is on its own
     uint32_t *x = blk_all[wv];
     const uint32_t *st = a.states + (size_t)j * MTN;
+    const long long gj = a.first + j;   // the stream's index on the tape
     for (int i = lane; i < MTN; i += 64) {
         const uint32_t v = st[i];
         x[i] = v;
-        if (j == 0) a.xraw[i] = v;
+        if (gj == 0) a.xraw[i] = v;
     }
     mt_wave_sync();
     const long long stride = 1ll << a.log2_stride;
     uint32_t *out = a.xraw + (size_t)j * (size_t)stride + MTN;   // the stream's words [0, stride)
-    static_assert(((1ll << 18) % MTN) % 64 == 0 && ((1ll << 19) % MTN) % 64 == 0 && ((1ll << 20) % MTN) % 64 == 0,
-                  "the last block of a stream must end on a sub-step boundary");
-    const long long left = a.words - (long long)j * stride;
+    const long long left = a.words - gj * stride;
     const uint32_t nwords = left >= stride ? (uint32_t)stride : left > 0 ? (uint32_t)left : 0u;   // a short round stops early
     for (uint32_t w0 = 0; w0 < nwords; w0 += MTN) {   // the classic in-place block update, 3 + 3 + 3 + 1 sub-steps
         const uint32_t remaining = nwords - w0;
@@ -331,17 +331,24 @@ __device__ __forceinline__ double mt_canonical(uint32_t w0, uint32_t w1) {
     return r;
 }
 
+// The word tape of a round is addressed by GLOBAL word index: word 0 = first of the 624 state words the round starts from, the
+// generated words follow from 624 on.  A context holds a WINDOW of it -- xraw[0] is tape word xbase -- which is the whole round on one
+// GPU and the sub-streams a shard needs when several GPUs share a round.  Attempt a (global) draws tape words p + 4a .. p + 4a + 3.
 struct PolarArgs {
     const uint32_t *xraw;
-    long long p;              // first unread word
-    long long attempts;       // attempts available: words p + 4a .. p + 4a + 3, a < attempts
-    uint32_t *blockcnt;                     // pass 0 out
-    const unsigned long long *blockbase;    // pass 1 in
-    const unsigned long long *total;        // pass 1 in: accepted attempts of the round
-    unsigned long long need;                // items wanted from this round
-    int per_frame;                          // 0: items are samples; else samples per frame (only whole frames are emitted)
-    long long *end_t;                       // pass 1 out: word after the last emitted item's draws
-    double *out;                            // samples, or LLR rows [row_hi - row_lo][N]; may be null (skip)
+    long long xbase;          // tape index of xraw[0]
+    long long p;              // tape index of the first unread word
+    long long at_lo, at_hi;   // this launch covers attempts [at_lo, at_hi)
+    unsigned long long base0; // accepted attempts before at_lo == item index of the first accepted attempt of the range
+    unsigned long long need;  // items wanted from this round
+    int per_frame;            // 0: items are samples; else samples per frame (the caller keeps whole frames only)
+    double *out;              // samples, or LLR rows [row_hi - row_lo][N]; may be null (skip)
+    // look-back state of the fused pass
+    unsigned long long *status;   // [blocks] (flag << 62) | value; zeroed by the host
+    unsigned *ticket;             // block id dispenser; zeroed by the host
+    // count-only mode: accepted attempts below / from split_at
+    long long split_at;
+    unsigned long long *counters; // [2]
     // frame mode
     long long first_frame;                  // global index of frame 0 of this round (codeword choice)
     long long row_lo, row_hi;               // frames of this round whose rows are written (a shard's slice)
@@ -351,30 +358,46 @@ struct PolarArgs {
     double sigma, punct_val;
 };
 
-constexpr int kPolarSub = 8;   // a wave takes 64 * 8 consecutive attempts, a workgroup 4 waves
+constexpr int kPolarSub = 8;                       // a wave takes 64 * 8 consecutive attempts, a workgroup 4 waves
+constexpr int kPolarBlock = 256 * kPolarSub;       // attempts per workgroup
+constexpr unsigned long long kStAgg = 1ull << 62, kStPrefix = 2ull << 62, kStMask = (1ull << 62) - 1ull;
 
-template <int PASS>
+__device__ __forceinline__ unsigned long long mt_wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// MODE 0: count only (two counters, split at an attempt index).  MODE 1: the fused pass -- every workgroup tests its attempts,
+// obtains the number of accepted attempts in front of it by DECOUPLED LOOK-BACK over the status words of its predecessors
+// (Merrill & Garland 2016: a workgroup publishes its own count at once, then sums its predecessors' counts backwards until it
+// meets one that already knows its prefix), and emits.  The word stream is read once.  Workgroups number themselves from an atomic
+// ticket, so every predecessor of a running workgroup is itself running or done and none of them waits for a successor: the
+// look-back always terminates.
+template <int MODE>
 __global__ void __launch_bounds__(256) mt_polar_kernel(const PolarArgs a) {
     __shared__ uint32_t wsum[4];
+    __shared__ unsigned long long s_excl;
+    __shared__ unsigned s_block;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long long a0 = (long long)blockIdx.x * (256 * kPolarSub) + (long long)wv * (64 * kPolarSub);
-    unsigned long long base = 0, limit = 0;
-    if (PASS == 1) {
-        base = a.blockbase[blockIdx.x];
-        limit = *a.total < a.need ? *a.total : a.need;
-        if (a.per_frame) limit -= limit % (unsigned long long)a.per_frame;
-        if (base >= limit) return;   // uniform over the workgroup
+    unsigned block = blockIdx.x;
+    if (MODE == 1) {
+        if (tid == 0) s_block = atomicAdd(a.ticket, 1u);
+        __syncthreads();
+        block = s_block;
     }
+    const long long a0 = a.at_lo + (long long)block * kPolarBlock + (long long)wv * (64 * kPolarSub);
+    const uint32_t *const xw = a.xraw + (a.p - a.xbase);
     double ys[kPolarSub], r2s[kPolarSub];
     unsigned long long bal[kPolarSub];
-    uint32_t mine = 0;
+    uint32_t mine = 0, below = 0;
 #pragma unroll
     for (int sub = 0; sub < kPolarSub; ++sub) {
         const long long at = a0 + sub * 64 + lane;
         bool ok = false;
         ys[sub] = 0; r2s[sub] = 1;
-        if (at < a.attempts) {
-            const uint32_t *w = a.xraw + a.p + 4 * at;
+        if (at < a.at_hi) {
+            const uint32_t *w = xw + 4 * at;
             const double u0 = mt_canonical(mt_temper(w[0]), mt_temper(w[1]));
             const double u1 = mt_canonical(mt_temper(w[2]), mt_temper(w[3]));
             const double x = 2.0 * u0 - 1.0;               // random.tcc:1821-1825
@@ -385,25 +408,59 @@ __global__ void __launch_bounds__(256) mt_polar_kernel(const PolarArgs a) {
         }
         bal[sub] = __ballot(ok);
         mine += (uint32_t)__popcll(bal[sub]);
+        if (MODE == 0) below += (uint32_t)__popcll(__ballot(ok && at < a.split_at));
+    }
+    if (MODE == 0) {
+        if (lane == 0 && mine) {
+            if (below) atomicAdd(&a.counters[0], (unsigned long long)below);
+            if (mine - below) atomicAdd(&a.counters[1], (unsigned long long)(mine - below));
+        }
+        return;
     }
     if (lane == 0) wsum[wv] = mine;
     __syncthreads();
-    if (PASS == 0) {
-        if (tid == 0) a.blockcnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        return;
+    if (wv == 0) {
+        const unsigned long long agg = (unsigned long long)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        unsigned long long excl = a.base0;
+        if (block > 0) {
+            if (lane == 0) __hip_atomic_store(&a.status[block], kStAgg | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long run = 0;
+            long long win = (long long)block - 1;   // nearest predecessor of the window; lane i looks at win - i
+            for (;;) {
+                const long long pred = win - lane;
+                // block "-1" knows its prefix: base0; anything in front of it is never reached
+                const unsigned long long st = pred >= 0 ? __hip_atomic_load(&a.status[pred], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                        : (kStPrefix | (pred == -1 ? a.base0 : 0ull));
+                const unsigned flag = (unsigned)(st >> 62);
+                const unsigned long long inval = __ballot(flag == 0u), pref = __ballot(flag == 2u);
+                if (pref) {
+                    const int fp = __ffsll((long long)pref) - 1;                 // nearest predecessor that knows its prefix
+                    if (inval & ((1ull << fp) - 1ull)) { __builtin_amdgcn_s_sleep(1); continue; }   // someone nearer has not published yet
+                    run += mt_wave_sum(lane <= fp ? (st & kStMask) : 0ull);
+                    break;
+                }
+                if (inval) { __builtin_amdgcn_s_sleep(1); continue; }
+                run += mt_wave_sum(st & kStMask);
+                win -= 64;
+            }
+            excl = run;
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&a.status[block], kStPrefix | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+        }
     }
-    unsigned long long g0 = base;
+    __syncthreads();
+    if (!a.out) return;
+    unsigned long long g0 = s_excl;
     for (int v = 0; v < wv; ++v) g0 += wsum[v];
-    if (g0 >= limit) return;
+    if (g0 >= a.need) return;
 #pragma unroll
     for (int sub = 0; sub < kPolarSub; ++sub) {
         const bool ok = (bal[sub] >> lane) & 1ull;
         const unsigned long long g = g0 + (unsigned long long)__popcll(bal[sub] & ((1ull << lane) - 1ull));
         g0 += (unsigned long long)__popcll(bal[sub]);
-        if (!ok || g >= limit) continue;
-        const long long at = a0 + sub * 64 + lane;
-        if (g + 1 == limit) *a.end_t = a.p + 4 * (at + 1);
-        if (!a.out) continue;
+        if (!ok || g >= a.need) continue;
         long long f = 0;
         int i = 0;
         if (a.per_frame) {   // a shard only evaluates the samples of its own frames
@@ -426,31 +483,82 @@ __global__ void __launch_bounds__(256) mt_polar_kernel(const PolarArgs a) {
     }
 }
 
-// exclusive scan of the per-block counts (one workgroup; nb is a few 10^4)
-__global__ void __launch_bounds__(1024) mt_scan_kernel(const uint32_t *cnt, unsigned long long *base, unsigned long long *total, long long nb,
-                                                       long long *end_t, long long end_preset) {
-    __shared__ unsigned long long part[1024];
-    const int tid = threadIdx.x;
-    if (tid == 0) *end_t = end_preset;   // where the generator stays if the emit pass emits nothing
-    const long long per = (nb + 1023) / 1024, lo = per * tid, hi = lo + per < nb ? lo + per : nb;
-    unsigned long long s = 0;
-    for (long long i = lo; i < hi; ++i) s += cnt[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned long long v = tid >= o ? part[tid - o] : 0ull;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    unsigned long long run = part[tid] - s;
-    for (long long i = lo; i < hi; ++i) { base[i] = run; run += cnt[i]; }
-    if (tid == 1023) *total = part[1023];
-}
+// After the fused pass: where does the generator continue?  Item `limit` - 1 is the last one the round keeps (limit = min(accepted,
+// need), whole frames only in frame mode; the host passes it when several GPUs share the round, else it is computed here from this
+// launch's own total).  The workgroup that holds that item is found by bisection over the inclusive prefixes the look-back left in
+// status[]; its attempts are tested once more to locate the attempt itself; the 624 words behind its draws become the state.
+struct FinishArgs {
+    PolarArgs pa;
+    long long blocks;
+    long long limit_in;        // -1: compute from this launch's total
+    long long end_preset;      // tape index where the generator stays if nothing is kept
+    long long xwords;          // words in the window (bounds check for the adopt)
+    unsigned long long *total; // [0] accepted attempts in [at_lo, at_hi); [1] limit used
+    long long *end_t;          // [0] tape index of the next unread word; [1] 1 if this launch found it (state adopted)
+    uint32_t *state;           // [624] out
+};
 
-// the generator continues at word *end_t: its state is the 624 words from there, position 0
-__global__ void __launch_bounds__(640) mt_adopt_kernel(const uint32_t *xraw, const long long *end_t, uint32_t *state) {
-    if (threadIdx.x < MTN) state[threadIdx.x] = xraw[*end_t + threadIdx.x];
+__global__ void __launch_bounds__(256) mt_finish_kernel(const FinishArgs f) {
+    __shared__ uint32_t wsum[4];
+    __shared__ long long s_end;
+    const PolarArgs &a = f.pa;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    auto incl = [&](long long b) -> unsigned long long { return b < 0 ? a.base0 : (a.status[b] & kStMask); };
+    const unsigned long long last = incl(f.blocks - 1);   // items in front of the end of this range
+    unsigned long long limit;
+    if (f.limit_in >= 0) limit = (unsigned long long)f.limit_in;
+    else {
+        limit = last < a.need ? last : a.need;
+        if (a.per_frame) limit -= limit % (unsigned long long)a.per_frame;
+    }
+    if (tid == 0) { f.total[0] = last - a.base0; f.total[1] = limit; s_end = -1; }
+    __syncthreads();
+    if (limit == 0) {
+        if (a.at_lo == 0 && tid == 0) s_end = f.end_preset;   // nothing kept: the range that starts the round leaves the generator where it was
+    } else if (limit - 1 >= a.base0 && limit - 1 < last) {
+        long long lo = 0, hi = f.blocks - 1;                  // smallest block whose inclusive prefix reaches `limit`
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (incl(mid) >= limit) hi = mid; else lo = mid + 1;
+        }
+        const unsigned long long rank = limit - 1 - incl(lo - 1);   // which accepted attempt of that block (0-based)
+        const long long a0 = a.at_lo + lo * kPolarBlock + (long long)wv * (64 * kPolarSub);
+        const uint32_t *const xw = a.xraw + (a.p - a.xbase);
+        unsigned long long bal[kPolarSub];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int sub = 0; sub < kPolarSub; ++sub) {
+            const long long at = a0 + sub * 64 + lane;
+            bool ok = false;
+            if (at < a.at_hi) {
+                const uint32_t *w = xw + 4 * at;
+                const double u0 = mt_canonical(mt_temper(w[0]), mt_temper(w[1]));
+                const double u1 = mt_canonical(mt_temper(w[2]), mt_temper(w[3]));
+                const double x = 2.0 * u0 - 1.0, y = 2.0 * u1 - 1.0;
+                const double r2 = x * x + y * y;
+                ok = !(r2 > 1.0 || r2 == 0.0);
+            }
+            bal[sub] = __ballot(ok);
+            mine += (uint32_t)__popcll(bal[sub]);
+        }
+        if (lane == 0) wsum[wv] = mine;
+        __syncthreads();
+        unsigned long long g0 = 0;
+        for (int v = 0; v < wv; ++v) g0 += wsum[v];
+#pragma unroll
+        for (int sub = 0; sub < kPolarSub; ++sub) {
+            const bool ok = (bal[sub] >> lane) & 1ull;
+            const unsigned long long g = g0 + (unsigned long long)__popcll(bal[sub] & ((1ull << lane) - 1ull));
+            g0 += (unsigned long long)__popcll(bal[sub]);
+            if (ok && g == rank) s_end = a.p + 4 * (a0 + sub * 64 + lane + 1);   // the word after this attempt's four
+        }
+    }
+    __syncthreads();
+    const long long end = s_end;
+    const bool found = end >= 0 && end - a.xbase >= 0 && end - a.xbase + MTN <= f.xwords;
+    if (found)
+        for (int i = tid; i < MTN; i += 256) f.state[i] = a.xraw[end - a.xbase + i];   // the generator continues there, position 0
+    if (tid == 0) { f.end_t[0] = end; f.end_t[1] = found ? 1 : 0; }
 }
 
 // per-context device state of the generator (ldpc_hip_mt_* entry points)
@@ -458,23 +566,25 @@ struct DeviceState {
     bool set = false;
     int pos = 0;                         // next word of d_state to draw (0..624); 0 after every generation round
     uint32_t *d_state = nullptr;         // [624]
+    uint32_t *d_state_next = nullptr;    // [624] where the finish kernel leaves the state the round ends in
     uint32_t *d_bits = nullptr;          // [kLevels][kMaxBits] exponents of the jump polynomials
     uint32_t *d_states = nullptr;        // [cap_streams][624]
     int cap_streams = 0;
     uint32_t *d_xraw = nullptr;          // [cap_words]
     size_t cap_words = 0;
-    uint32_t *d_blockcnt = nullptr;
-    unsigned long long *d_blockbase = nullptr;
+    unsigned long long *d_status = nullptr;   // [cap_blocks] look-back status words of the fused pass
     long long cap_blocks = 0;
-    unsigned long long *d_total = nullptr;
-    long long *d_end_t = nullptr;
+    unsigned *d_ticket = nullptr;
+    unsigned long long *d_counters = nullptr; // [2] count-only mode
+    unsigned long long *d_total = nullptr;    // [2] accepted in range, limit used
+    long long *d_end_t = nullptr;             // [2] next unread word, found flag
     long long frames_taken = 0;          // frames drawn since ldpc_hip_mt_set_state (codeword choice f % ncw)
     int32_t *d_info = nullptr, *d_iters = nullptr;
     long long cap_rec = 0;
 };
 
 inline void release(DeviceState &m) {
-    void *ptrs[] = {m.d_state, m.d_bits, m.d_states, m.d_xraw, m.d_blockcnt, m.d_blockbase, m.d_total, m.d_end_t, m.d_info, m.d_iters};
+    void *ptrs[] = {m.d_state, m.d_state_next, m.d_bits, m.d_states, m.d_xraw, m.d_status, m.d_ticket, m.d_counters, m.d_total, m.d_end_t, m.d_info, m.d_iters};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     m = DeviceState();
 }

@@ -9,8 +9,11 @@ int mt_prepare(ldpc_hip_ctx *c) {
     const ldpc_mt::JumpPolys &J = ldpc_mt::jump_polys();
     if (!J.ok) return fail(LDPC_HIP_EUNSUPPORTED, "mt19937 jump polynomials: %s", J.err.c_str());
     HIP_TRY(hipMalloc(&m.d_state, sizeof(uint32_t) * ldpc_mt::MTN));
+    HIP_TRY(hipMalloc(&m.d_state_next, sizeof(uint32_t) * ldpc_mt::MTN));
     HIP_TRY(hipMalloc(&m.d_total, sizeof(unsigned long long) * 2));
     HIP_TRY(hipMalloc(&m.d_end_t, sizeof(long long) * 2));
+    HIP_TRY(hipMalloc(&m.d_counters, sizeof(unsigned long long) * 2));
+    HIP_TRY(hipMalloc(&m.d_ticket, sizeof(unsigned) * 2));
     HIP_TRY(hipMalloc(&m.d_bits, sizeof(uint32_t) * J.bits.size()));
     HIP_TRY(hipMemcpy(m.d_bits, J.bits.data(), sizeof(uint32_t) * J.bits.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_mt::mt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -18,76 +21,238 @@ int mt_prepare(ldpc_hip_ctx *c) {
     return 0;
 }
 
-// One generation round on `st`: draws from the context's generator until `need` items exist or the round's words run out, emits
-// min(need, produced) items (whole frames when proto.per_frame != 0) through proto.out, and moves the generator to the word after
-// the last emitted item.  Synchronises the stream (the count of accepted attempts decides how far the round got).
-int mt_round(ldpc_hip_ctx *c, unsigned long long need, ldpc_mt::PolarArgs proto, unsigned long long *emitted, hipStream_t st) {
+// ---- one generation round, in pieces (a single context runs them back to back; ldpc_multi.hpp runs them per shard with the
+// exchange of the accepted-attempt counts in between) -------------------------------------------------------------------------
+
+// The round as a whole: how many attempts are on offer and how far the tape reaches (the same for every shard count).
+struct MtPlan {
+    unsigned long long need = 0;   // items wanted
+    long long pos = 0;             // tape index of the first unread word (0..624)
+    long long attempts = 0;        // attempts on offer: tape words pos + 4a .. pos + 4a + 3, a < attempts
+    long long tape_words = 0;      // generated words behind the first 624 (the last 624 of them stay unread: they can become the next state)
+    long long margin = 0;          // attempts by which the position of an item may be off its expectation (8 standard deviations + slack)
+};
+
+// A context's window of the tape: whole sub-streams of 2^ls words on the grid that starts at tape word 624.
+struct MtWindow {
+    int ls = ldpc_mt::kLog2Stride;
+    long long stride = 0, first = 0, S = 0;   // streams [first, first + S)
+    long long xbase = 0, xwords = 0;          // tape index of xraw[0], words in the window
+    long long gen_words = 0;                  // tape words behind the first 624 the window's streams produce (a multiple of 64)
+    long long at_lo = 0, at_hi = 0;           // attempts whose four words all lie inside the window
+};
+
+inline int mt_log2_stride(long long words) {
+    // stream length by the size of the job: the generate kernel is bound by the latency of one wave walking its stream, the jumps
+    // by their number -- short streams for small rounds, 2^20 words for the 65536-frame batches
+    return words <= (1ll << 26) ? 18 : words <= (1ll << 28) ? 19 : ldpc_mt::kLog2StrideMax;
+}
+
+MtPlan mt_plan(long long pos, unsigned long long need) {
     using namespace ldpc_mt;
-    DeviceState &m = c->mt;
+    MtPlan pl;
+    pl.need = need; pl.pos = pos;
     const double g = (double)need;
     // attempts for `need` accepted ones at p = pi/4, plus ~8 standard deviations (negative binomial: sd = 0.59 sqrt(need))
     const long long A = (long long)(g * 1.2732395447351628 + 5.0 * std::sqrt(g) + 64.0);
-    // stream length by the size of the round: the generate kernel is bound by the latency of one wave walking its stream, the
-    // jumps by their number -- short streams for small rounds, 2^20 words for the 65536-frame batches
-    const long long want = m.pos + 4 * A;
-    const int ls = want <= (1ll << 26) ? 18 : want <= (1ll << 28) ? 19 : kLog2StrideMax;
-    const long long stride = 1ll << ls;
+    const long long want = pos + 4 * A;
+    const long long stride = 1ll << mt_log2_stride(want);
     long long S = (want + stride - 1) / stride;
     if (S < 1) S = 1;
     if (S > kMaxStreams) S = kMaxStreams;
-    const size_t words = (size_t)MTN + (size_t)S * (size_t)stride;
-    if (S > m.cap_streams) {
+    long long attempts = (S * stride - pos) / 4;   // the last 624 words stay unread: they are the next state
+    if (attempts > A) attempts = A;               // a short round neither generates nor scans a whole stream
+    pl.attempts = attempts;
+    pl.tape_words = S * stride;
+    pl.margin = (long long)(4.8 * std::sqrt(g)) + 64;
+    return pl;
+}
+
+// the window that covers tape words [w_lo, w_hi) (w_hi <= 624 + tape_words) on a grid chosen by the window's own size
+MtWindow mt_window(const MtPlan &pl, long long w_lo, long long w_hi) {
+    using namespace ldpc_mt;
+    MtWindow w;
+    if (w_lo < 0) w_lo = 0;
+    if (w_hi > MTN + pl.tape_words) w_hi = MTN + pl.tape_words;
+    w.ls = mt_log2_stride(w_hi - w_lo);
+    w.stride = 1ll << w.ls;
+    w.first = w_lo <= MTN ? 0 : (w_lo - MTN) / w.stride;
+    long long last = w_hi <= MTN ? 1 : (w_hi - MTN + w.stride - 1) / w.stride;   // exclusive
+    if (last <= w.first) last = w.first + 1;
+    w.S = last - w.first;
+    w.xbase = w.first * w.stride;
+    long long gw = (w_hi - MTN + 63) / 64 * 64;                 // tape words behind the first 624 that are read or adopted
+    if (gw > last * w.stride) gw = last * w.stride;
+    if (gw > pl.tape_words) gw = pl.tape_words;
+    if (gw < 0) gw = 0;
+    w.gen_words = gw;
+    w.xwords = MTN + gw - w.xbase;
+    // attempts entirely inside [window start, 624 + gen_words)
+    const long long t_lo = w.first == 0 ? 0 : MTN + w.xbase;    // first tape word the window holds
+    w.at_lo = t_lo <= pl.pos ? 0 : (t_lo - pl.pos + 3) / 4;
+    w.at_hi = (MTN + gw - pl.pos) / 4;
+    if (w.at_hi > pl.attempts) w.at_hi = pl.attempts;
+    if (w.at_hi < w.at_lo) w.at_hi = w.at_lo;
+    return w;
+}
+
+int mt_ensure(ldpc_hip_ctx *c, const MtWindow &w) {
+    using namespace ldpc_mt;
+    DeviceState &m = c->mt;
+    const long long slots = w.S + 2;   // + two scratch states for the chain of jumps to the window's first stream
+    if (slots > m.cap_streams) {
         if (m.d_states) (void)hipFree(m.d_states);
         m.d_states = nullptr; m.cap_streams = 0;
-        HIP_TRY(hipMalloc(&m.d_states, sizeof(uint32_t) * MTN * (size_t)S));
-        m.cap_streams = (int)S;
+        HIP_TRY(hipMalloc(&m.d_states, sizeof(uint32_t) * MTN * (size_t)slots));
+        m.cap_streams = (int)slots;
     }
+    const size_t words = (size_t)MTN + (size_t)w.S * (size_t)w.stride + 64;
     if (words > m.cap_words) {
         if (m.d_xraw) (void)hipFree(m.d_xraw);
         m.d_xraw = nullptr; m.cap_words = 0;
         HIP_TRY(hipMalloc(&m.d_xraw, sizeof(uint32_t) * words));
         m.cap_words = words;
     }
-    long long attempts = (S * stride - m.pos) / 4;   // the last 624 words stay unread: they are the next state
-    if (attempts > A) attempts = A;                              // a short round neither generates nor scans a whole stream
-    long long gen_words = (m.pos + 4 * attempts + 63) / 64 * 64;  // words behind the first 624 that the round reads or adopts
-    if (gen_words > S * stride) gen_words = S * stride;
-    const long long nb = (attempts + 256 * kPolarSub - 1) / (256 * kPolarSub);
+    const long long nb = (w.at_hi - w.at_lo + kPolarBlock - 1) / kPolarBlock + 1;
     if (nb > m.cap_blocks) {
-        if (m.d_blockcnt) (void)hipFree(m.d_blockcnt);
-        if (m.d_blockbase) (void)hipFree(m.d_blockbase);
-        m.d_blockcnt = nullptr; m.d_blockbase = nullptr; m.cap_blocks = 0;
-        HIP_TRY(hipMalloc(&m.d_blockcnt, sizeof(uint32_t) * (size_t)nb));
-        HIP_TRY(hipMalloc(&m.d_blockbase, sizeof(unsigned long long) * (size_t)nb));
+        if (m.d_status) (void)hipFree(m.d_status);
+        m.d_status = nullptr; m.cap_blocks = 0;
+        HIP_TRY(hipMalloc(&m.d_status, sizeof(unsigned long long) * (size_t)nb));
         m.cap_blocks = nb;
     }
-    HIP_TRY(hipMemcpyAsync(m.d_states, m.d_state, sizeof(uint32_t) * MTN, hipMemcpyDeviceToDevice, st));
-    if (S > 1) HIP_TRY(hipMemsetAsync(m.d_states + MTN, 0, sizeof(uint32_t) * MTN * (size_t)(S - 1), st));   // the jumps XOR into them
+    return 0;
+}
+
+// start states of the window's streams (d_states[0 .. S)), then the words themselves (d_xraw)
+int mt_generate(ldpc_hip_ctx *c, const MtWindow &w, hipStream_t st) {
+    using namespace ldpc_mt;
+    DeviceState &m = c->mt;
     const JumpPolys &J = jump_polys();
-    for (int level = 0; (1ll << level) < S; ++level) {   // stream j + 2^level from stream j, j < 2^level
-        const long long have = 1ll << level, cnt = have < S - have ? have : S - have;
+    const size_t pl0 = (size_t)(w.ls - kLog2Stride);
+    uint32_t *t0 = m.d_states + (size_t)MTN * (size_t)w.S, *t1 = t0 + MTN;
+    if (w.first == 0) {
+        HIP_TRY(hipMemcpyAsync(m.d_states, m.d_state, sizeof(uint32_t) * MTN, hipMemcpyDeviceToDevice, st));
+    } else {
+        // the state first * stride words on: one jump per set bit of `first` (x^(a+b) = x^a x^b), through two scratch slots
+        HIP_TRY(hipMemcpyAsync(t0, m.d_state, sizeof(uint32_t) * MTN, hipMemcpyDeviceToDevice, st));
+        for (int e = 0; (w.first >> e) != 0; ++e) {
+            if (!((w.first >> e) & 1)) continue;
+            const size_t pl = pl0 + (size_t)e;
+            if (pl >= (size_t)kLevels) return fail(LDPC_HIP_EUNSUPPORTED, "exact-replay window starts beyond 2^%d words", kLog2Stride + kLevels);
+            HIP_TRY(hipMemsetAsync(t1, 0, sizeof(uint32_t) * MTN, st));
+            JumpArgs ja{m.d_states, m.d_bits + pl * kMaxBits, J.nbits[pl], 8, (int)(t0 - m.d_states) / MTN, (int)(t1 - m.d_states) / MTN};
+            hipLaunchKernelGGL(mt_jump_kernel, dim3(8), dim3(640), sizeof(uint32_t) * kSeqWords, st, ja);
+            uint32_t *t = t0; t0 = t1; t1 = t;
+        }
+        HIP_TRY(hipMemcpyAsync(m.d_states, t0, sizeof(uint32_t) * MTN, hipMemcpyDeviceToDevice, st));
+    }
+    if (w.S > 1) HIP_TRY(hipMemsetAsync(m.d_states + MTN, 0, sizeof(uint32_t) * MTN * (size_t)(w.S - 1), st));   // the jumps XOR into them
+    for (int level = 0; (1ll << level) < w.S; ++level) {   // stream j + 2^level from stream j, j < 2^level
+        const long long have = 1ll << level, cnt = have < w.S - have ? have : w.S - have;
         const int parts = cnt >= 256 ? 1 : cnt >= 128 ? 2 : cnt >= 64 ? 4 : 8;   // few jumps: spread each over several CUs
-        const size_t pl = (size_t)(ls - kLog2Stride + level);   // the polynomial of 2^(ls + level) words
+        const size_t pl = pl0 + (size_t)level;   // the polynomial of 2^(ls + level) words
         JumpArgs ja{m.d_states, m.d_bits + pl * kMaxBits, J.nbits[pl], parts, 0, (int)have};
         hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(cnt * parts)), dim3(640), sizeof(uint32_t) * kSeqWords, st, ja);
     }
-    GenArgs ga{m.d_states, m.d_xraw, (int)S, ls, gen_words};
-    hipLaunchKernelGGL(mt_generate_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, ga);
-    proto.xraw = m.d_xraw; proto.p = m.pos; proto.attempts = attempts;
-    proto.blockcnt = m.d_blockcnt; proto.blockbase = m.d_blockbase; proto.total = m.d_total; proto.need = need; proto.end_t = m.d_end_t;
-    hipLaunchKernelGGL(mt_polar_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, proto);
-    hipLaunchKernelGGL(mt_scan_kernel, dim3(1), dim3(1024), 0, st, m.d_blockcnt, m.d_blockbase, m.d_total, nb, m.d_end_t, (long long)m.pos);
-    hipLaunchKernelGGL(mt_polar_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, proto);
-    hipLaunchKernelGGL(mt_adopt_kernel, dim3(1), dim3(640), 0, st, m.d_xraw, m.d_end_t, m.d_state);
+    GenArgs ga{m.d_states, m.d_xraw, (int)w.S, w.first, w.ls, w.gen_words};
+    hipLaunchKernelGGL(mt_generate_kernel, dim3((unsigned)((w.S + 3) / 4)), dim3(256), 0, st, ga);
     HIP_TRY(hipGetLastError());
-    unsigned long long total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, m.d_total, sizeof total, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    m.pos = 0;
-    unsigned long long lim = total < need ? total : need;
-    if (proto.per_frame) lim -= lim % (unsigned long long)proto.per_frame;
-    *emitted = lim;
     return 0;
+}
+
+void mt_fill(ldpc_hip_ctx *c, const MtPlan &pl, const MtWindow &w, ldpc_mt::PolarArgs &a) {
+    a.xraw = c->mt.d_xraw; a.xbase = w.xbase; a.p = pl.pos; a.need = pl.need;
+    a.status = c->mt.d_status; a.ticket = c->mt.d_ticket; a.counters = c->mt.d_counters;
+}
+
+// accepted attempts in [at_lo, split) and [split, at_hi) -> d_counters[0], [1] (asynchronous)
+int mt_count(ldpc_hip_ctx *c, const MtPlan &pl, const MtWindow &w, long long at_lo, long long split, long long at_hi, hipStream_t st) {
+    using namespace ldpc_mt;
+    PolarArgs a{};
+    mt_fill(c, pl, w, a);
+    a.at_lo = at_lo; a.at_hi = at_hi; a.split_at = split;
+    HIP_TRY(hipMemsetAsync(c->mt.d_counters, 0, sizeof(unsigned long long) * 2, st));
+    const long long nb = (at_hi - at_lo + kPolarBlock - 1) / kPolarBlock;
+    if (nb > 0) hipLaunchKernelGGL(mt_polar_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// the fused pass over the window's attempts; base0 = accepted attempts in front of w.at_lo (asynchronous)
+int mt_emit(ldpc_hip_ctx *c, const MtPlan &pl, const MtWindow &w, ldpc_mt::PolarArgs a, unsigned long long base0, hipStream_t st) {
+    using namespace ldpc_mt;
+    mt_fill(c, pl, w, a);
+    a.at_lo = w.at_lo; a.at_hi = w.at_hi; a.base0 = base0;
+    const long long nb = (w.at_hi - w.at_lo + kPolarBlock - 1) / kPolarBlock;
+    HIP_TRY(hipMemsetAsync(c->mt.d_ticket, 0, sizeof(unsigned), st));
+    if (nb > 0) {
+        HIP_TRY(hipMemsetAsync(c->mt.d_status, 0, sizeof(unsigned long long) * (size_t)nb, st));
+        hipLaunchKernelGGL(mt_polar_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// where the generator continues (limit_in < 0: decided from this window's own total) -> d_total[2], d_end_t[2], d_state when found
+int mt_finish(ldpc_hip_ctx *c, const MtPlan &pl, const MtWindow &w, ldpc_mt::PolarArgs a, unsigned long long base0, long long limit_in, hipStream_t st) {
+    using namespace ldpc_mt;
+    mt_fill(c, pl, w, a);
+    a.at_lo = w.at_lo; a.at_hi = w.at_hi; a.base0 = base0;
+    FinishArgs f{};
+    f.pa = a;
+    f.blocks = (w.at_hi - w.at_lo + kPolarBlock - 1) / kPolarBlock;
+    f.limit_in = limit_in; f.end_preset = pl.pos; f.xwords = w.xwords;
+    f.total = c->mt.d_total; f.end_t = c->mt.d_end_t; f.state = c->mt.d_state_next;   // committed by the caller once the round is known to be good
+    hipLaunchKernelGGL(mt_finish_kernel, dim3(1), dim3(256), 0, st, f);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// One generation round on one context, whole tape: draws from the context's generator until `need` items exist or the round's
+// words run out, emits min(need, produced) items (whole frames when proto.per_frame != 0) through proto.out, and moves the generator
+// to the word after the last emitted item.  Synchronises the stream (the count of accepted attempts decides how far the round got).
+int mt_round(ldpc_hip_ctx *c, unsigned long long need, ldpc_mt::PolarArgs proto, unsigned long long *emitted, hipStream_t st) {
+    using namespace ldpc_mt;
+    DeviceState &m = c->mt;
+    const MtPlan pl = mt_plan(m.pos, need);
+    const MtWindow w = mt_window(pl, 0, pl.pos + 4 * pl.attempts + MTN);
+    if (int rc = mt_ensure(c, w)) return rc;
+    if (int rc = mt_generate(c, w, st)) return rc;
+    if (int rc = mt_emit(c, pl, w, proto, 0ull, st)) return rc;
+    if (int rc = mt_finish(c, pl, w, proto, 0ull, -1, st)) return rc;
+    HIP_TRY(hipMemcpyAsync(m.d_state, m.d_state_next, sizeof(uint32_t) * MTN, hipMemcpyDeviceToDevice, st));
+    unsigned long long tot[2] = {0, 0};
+    long long endt[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(tot, m.d_total, sizeof tot, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(endt, m.d_end_t, sizeof endt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (endt[1] != 1) return fail(LDPC_HIP_EHIP, "exact-replay generator: the end of the round was not found (limit %llu of %llu accepted)", tot[1], tot[0]);
+    m.pos = 0;
+    *emitted = tot[1];
+    return 0;
+}
+
+// what the emit pass needs to turn samples into decoder inputs of this context's chain (bp_simulation.cpp:603/610, :684, :697-710)
+int mt_frame_proto(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, ldpc_mt::PolarArgs &a) {
+    using namespace ldpc_mt;
+    if (!c->mt.set) return fail(LDPC_HIP_EINVAL, "the generator has no state: call ldpc_hip_mt_set_state first");
+    if (modulation_type != 0 && modulation_type != 1)
+        return fail(LDPC_HIP_EUNSUPPORTED, "exact replay covers modulation_type 0 (BPSK) and 1 (QAM4): upstream's QAM16+ wiring is broken (SURVEY Appendix B Q5/Q6)");
+    if ((unsigned long long)c->N > kRoundItems) return fail(LDPC_HIP_EUNSUPPORTED, "code length %d is beyond one generation round", c->N);
+    a = PolarArgs{};
+    if (int rc = awgn_sigma(c, snr_db, modulation_type, punctured_blocks, &a.sigma)) return rc;
+    if (int rc = prepare_chain(c, modulation_type)) return rc;
+    a.per_frame = c->N;
+    a.tx = c->ncw > 0 ? c->d_tx : nullptr; a.ncw = c->ncw > 0 ? c->ncw : 1; a.ntx = c->chain_ntx;
+    a.scatter = c->d_scatter;
+    a.punct_start = c->N - c->M * punctured_blocks;
+    a.punct_val = (c->decoder_id == LDPC_HIP_SP_DEC || c->decoder_id == LDPC_HIP_TASP_DEC || c->decoder_id == LDPC_HIP_ASP_DEC) ? 0.0 : 0.5;  // :700 (sic)
+    return 0;
+}
+
+inline long long mt_frames_per_round(const ldpc_hip_ctx *c) {
+    const long long per = (long long)(ldpc_mt::kRoundItems / (unsigned long long)c->N);
+    return per > 0 ? per : 1;
 }
 
 // LLR rows of the next B frames of the generator's stream; of those, frames [lo, hi) are written to d_rows ([hi - lo][N]); d_rows
@@ -96,19 +261,9 @@ int mt_llr_rows(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctur
                 double *d_rows, hipStream_t st) {
     using namespace ldpc_mt;
     DeviceState &m = c->mt;
-    if (!m.set) return fail(LDPC_HIP_EINVAL, "the generator has no state: call ldpc_hip_mt_set_state first");
-    if (modulation_type != 0 && modulation_type != 1)
-        return fail(LDPC_HIP_EUNSUPPORTED, "exact replay covers modulation_type 0 (BPSK) and 1 (QAM4): upstream's QAM16+ wiring is broken (SURVEY Appendix B Q5/Q6)");
-    if ((unsigned long long)c->N > kRoundItems) return fail(LDPC_HIP_EUNSUPPORTED, "code length %d is beyond one generation round", c->N);
     PolarArgs a{};
-    if (int rc = awgn_sigma(c, snr_db, modulation_type, punctured_blocks, &a.sigma)) return rc;
-    if (int rc = prepare_chain(c, modulation_type)) return rc;
-    a.per_frame = c->N;
-    a.tx = c->ncw > 0 ? c->d_tx : nullptr; a.ncw = c->ncw > 0 ? c->ncw : 1; a.ntx = c->chain_ntx;
-    a.scatter = c->d_scatter;
-    a.punct_start = c->N - c->M * punctured_blocks;
-    a.punct_val = (c->decoder_id == LDPC_HIP_SP_DEC || c->decoder_id == LDPC_HIP_TASP_DEC || c->decoder_id == LDPC_HIP_ASP_DEC) ? 0.0 : 0.5;  // :700 (sic)
-    const long long per_round = (long long)(kRoundItems / (unsigned long long)c->N) > 0 ? (long long)(kRoundItems / (unsigned long long)c->N) : 1;
+    if (int rc = mt_frame_proto(c, snr_db, modulation_type, punctured_blocks, a)) return rc;
+    const long long per_round = mt_frames_per_round(c);
     long long done = 0;
     int stalled = 0;
     while (done < B) {

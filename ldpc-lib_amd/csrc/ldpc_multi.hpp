@@ -196,6 +196,7 @@ struct ldpc_hip_multi {
     std::unique_ptr<ldpc_multi::ShardPool> pool;  // n > 1: one thread per shard
     std::string reduction = "host";
     int test_fail_shard = -1;                  // LDPC_HIP_TEST_FAIL_SHARD: this shard's enqueue fails (tests of the failure path)
+    long long mt_sharded_rounds = 0, mt_fallbacks = 0;   // exact replay: generation rounds shared out / redone with the whole tape per shard
 };
 
 namespace {
@@ -472,8 +473,243 @@ int ldpc_hip_decode_host_multi(ldpc_hip_multi *m, double *llr, long long B, int 
     });
 }
 
-// ---- exact replay over the shards: every shard runs the SAME generator over the whole batch (the stream is sequential by nature)
-// and decodes its contiguous slice of the frames; no exchange at all.
+// ---- exact replay over the shards ---------------------------------------------------------------------------------------------
+// The generator's stream is sequential, but jump-ahead reaches any point of it: the round's word tape is cut at the EXPECTED positions
+// of the shards' first items, every shard makes the sub-streams around its cut (+- 8 standard deviations of where the items can
+// lie) and counts the accepted polar-method attempts of its own stretch; the n counts go through the host (a counters-only
+// exchange, like the error counters), after which every shard knows the item index its window starts at, emits the decoder inputs
+// of its own frames and -- the shard whose window holds the round's last item -- the state the generator is left in, which the
+// host copies to the others.  Per-shard generation work is ~1/n of the round.  If an estimate ever fails (an item outside its
+// shard's window) the round is redone with every shard generating the whole tape, so correctness never rests on the margins.
+}  // extern "C"
+
+namespace {
+
+bool mt_sharding_wanted(const ldpc_hip_multi *m, const MtPlan &pl) {
+    const int n = (int)m->shard.size();
+    if (n < 2) return false;
+    if (const char *e = getenv("LDPC_HIP_MT_SHARDED")) return atoi(e) != 0 && pl.attempts >= 2 * n;
+    return pl.attempts >= (long long)n * 16 * pl.margin;   // stretches much longer than the margins around them
+}
+
+// One generation round over `frames` frames for all shards (generators in the same state on entry and on return).  part[0..n]:
+// frame boundaries of the shards' stretches; shard i writes the rows of its frames into its workspace when `rows` is set.
+// *fdone = frames completed (whole frames; a round may come up short).
+int multi_mt_round(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, long long frames, const std::vector<long long> &part,
+                   bool rows, long long *fdone) {
+    using namespace ldpc_mt;
+    const int n = (int)m->shard.size();
+    ldpc_hip_ctx *c0 = m->shard[0];
+    const long long N = c0->N;
+    const unsigned long long need = (unsigned long long)frames * (unsigned long long)N;
+    const MtPlan pl = mt_plan(c0->mt.pos, need);
+    std::vector<PolarArgs> proto((size_t)n);
+    auto shard_proto = [&](int i) -> int {
+        ldpc_hip_ctx *c = m->shard[(size_t)i];
+        if (int rc = mt_frame_proto(c, snr_db, modulation_type, punctured_blocks, proto[(size_t)i])) return rc;
+        PolarArgs &a = proto[(size_t)i];
+        a.first_frame = c->mt.frames_taken;
+        if (rows && part[(size_t)i] < part[(size_t)i + 1]) { a.row_lo = part[(size_t)i]; a.row_hi = part[(size_t)i + 1]; a.out = c->w_llr; }
+        else { a.row_lo = 0; a.row_hi = 0; a.out = nullptr; }
+        return 0;
+    };
+    bool sharded = mt_sharding_wanted(m, pl);
+    unsigned long long limit = 0;
+    if (sharded) {
+        // ---- phase A: windows, words, counts
+        std::vector<long long> cut((size_t)n + 1);   // attempt index where shard i's stretch is expected to start
+        for (int i = 0; i <= n; ++i) {
+            const long long at = (long long)((double)part[(size_t)i] * (double)N * 1.2732395447351628);
+            cut[(size_t)i] = i == 0 ? 0 : i == n ? pl.attempts : (at < pl.attempts ? at : pl.attempts);
+        }
+        std::vector<MtWindow> win((size_t)n);
+        std::vector<unsigned long long> cnt((size_t)n * 2, 0ull);
+        int rc = for_each_shard(m, [&](int i) -> int {
+            ldpc_hip_ctx *c = m->shard[(size_t)i];
+            if (int r = set_device(c)) return r;
+            if (i == m->test_fail_shard) return fail(LDPC_HIP_EHIP, "injected failure (LDPC_HIP_TEST_FAIL_SHARD)");
+            if (int r = shard_proto(i)) return r;
+            if (cut[(size_t)i] >= cut[(size_t)i + 1]) { win[(size_t)i] = MtWindow(); return 0; }   // nothing to own
+            hipStream_t st = m->stream[(size_t)i];
+            const long long a_lo = cut[(size_t)i] - pl.margin, a_hi = cut[(size_t)i + 1] + pl.margin;
+            MtWindow &w = win[(size_t)i];
+            w = mt_window(pl, pl.pos + 4 * (a_lo < 0 ? 0 : a_lo), pl.pos + 4 * (a_hi > pl.attempts ? pl.attempts : a_hi) + MTN);
+            if (int r = mt_ensure(c, w)) return r;
+            if (int r = mt_generate(c, w, st)) return r;
+            if (int r = mt_count(c, pl, w, w.at_lo, cut[(size_t)i], cut[(size_t)i + 1], st)) return r;
+            HIP_TRY(hipMemcpyAsync(&cnt[(size_t)i * 2], c->mt.d_counters, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            return 0;
+        });
+        if (rc) { const std::string e = g_err; drain_streams(m); return fail(rc, "%s", e.c_str()); }
+        for (int i = 0; i < n && sharded; ++i)   // a window must reach from its cut's margin to the next cut (it does unless the tape ended early)
+            if (win[(size_t)i].S > 0 && (win[(size_t)i].at_lo > cut[(size_t)i] || win[(size_t)i].at_hi < cut[(size_t)i + 1])) sharded = false;
+        if (sharded) {
+            // ---- the exchange: n counts -> item index in front of every stretch, the round's total, what the round keeps
+            std::vector<unsigned long long> before((size_t)n + 1, 0ull);
+            for (int i = 0; i < n; ++i) before[(size_t)i + 1] = before[(size_t)i] + cnt[(size_t)i * 2 + 1];
+            const unsigned long long total = before[(size_t)n];
+            limit = total < need ? total : need;
+            limit -= limit % (unsigned long long)N;
+            // ---- phase B: emit, find the end
+            std::vector<unsigned long long> tot((size_t)n * 2, 0ull);
+            std::vector<long long> endt((size_t)n * 2, 0ll);
+            rc = for_each_shard(m, [&](int i) -> int {
+                ldpc_hip_ctx *c = m->shard[(size_t)i];
+                const MtWindow &w = win[(size_t)i];
+                if (w.S == 0) return 0;
+                if (int r = set_device(c)) return r;
+                hipStream_t st = m->stream[(size_t)i];
+                const unsigned long long base0 = before[(size_t)i] - cnt[(size_t)i * 2];   // minus the accepted attempts of the left margin
+                if (int r = mt_emit(c, pl, w, proto[(size_t)i], base0, st)) return r;
+                if (int r = mt_finish(c, pl, w, proto[(size_t)i], base0, (long long)limit, st)) return r;
+                HIP_TRY(hipMemcpyAsync(&tot[(size_t)i * 2], c->mt.d_total, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(&endt[(size_t)i * 2], c->mt.d_end_t, sizeof(long long) * 2, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                return 0;
+            });
+            if (rc) { const std::string e = g_err; drain_streams(m); return fail(rc, "%s", e.c_str()); }
+            // ---- every shard's items inside its window?  who holds the end?
+            int owner = -1;
+            for (int i = 0; i < n; ++i) {
+                const MtWindow &w = win[(size_t)i];
+                if (w.S > 0 && endt[(size_t)i * 2 + 1] == 1 && owner < 0) owner = i;
+                const unsigned long long lo_item = (unsigned long long)part[(size_t)i] * (unsigned long long)N;
+                unsigned long long hi_item = (unsigned long long)part[(size_t)i + 1] * (unsigned long long)N;
+                if (hi_item > limit) hi_item = limit;
+                if (!rows || lo_item >= hi_item) continue;
+                const unsigned long long base0 = before[(size_t)i] - cnt[(size_t)i * 2];
+                if (w.S == 0 || base0 > lo_item || base0 + tot[(size_t)i * 2] < hi_item) sharded = false;
+            }
+            if (owner < 0) sharded = false;
+            if (sharded) {   // the state the round ends in: from the shard that found it to all
+                uint32_t st_words[MTN];
+                ldpc_hip_ctx *co = m->shard[(size_t)owner];
+                HIP_TRY(hipSetDevice(co->device));
+                HIP_TRY(hipMemcpy(st_words, co->mt.d_state_next, sizeof st_words, hipMemcpyDeviceToHost));
+                for (int i = 0; i < n; ++i) {
+                    ldpc_hip_ctx *c = m->shard[(size_t)i];
+                    HIP_TRY(hipSetDevice(c->device));
+                    HIP_TRY(hipMemcpy(c->mt.d_state, st_words, sizeof st_words, hipMemcpyHostToDevice));
+                    c->mt.pos = 0;
+                }
+            }
+        }
+        if (!sharded) ++m->mt_fallbacks;
+        else ++m->mt_sharded_rounds;
+    }
+    if (!sharded) {   // every shard generates the whole tape and emits its rows
+        std::vector<unsigned long long> emitted((size_t)n, 0ull);
+        const int rc = for_each_shard(m, [&](int i) -> int {
+            ldpc_hip_ctx *c = m->shard[(size_t)i];
+            if (int r = set_device(c)) return r;
+            if (int r = shard_proto(i)) return r;
+            return mt_round(c, need, proto[(size_t)i], &emitted[(size_t)i], m->stream[(size_t)i]);
+        });
+        if (rc) return rc;
+        limit = emitted[0];
+        for (int i = 1; i < n; ++i) if (emitted[(size_t)i] != limit) return fail(LDPC_HIP_EHIP, "exact replay: shards 0 and %d disagree on the round (%llu vs %llu items)", i, limit, emitted[(size_t)i]);
+    }
+    *fdone = (long long)(limit / (unsigned long long)N);
+    for (ldpc_hip_ctx *c : m->shard) c->mt.frames_taken += *fdone;
+    return 0;
+}
+
+// the next B frames of the stream: generated (sharded), and -- decode == true -- decoded and counted on the shard that holds their rows;
+// records in global frame order
+int multi_mt_frames(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha, long long B, bool decode,
+                    int32_t *frame_info, int32_t *iters) {
+    const int n = (int)m->shard.size();
+    ldpc_hip_ctx *c0 = m->shard[0];
+    for (ldpc_hip_ctx *c : m->shard) {
+        if (!c->mt.set) return fail(LDPC_HIP_EINVAL, "the generator has no state: call ldpc_hip_mt_set_state_multi first");
+        if (c->mt.pos != c0->mt.pos || c->mt.frames_taken != c0->mt.frames_taken) return fail(LDPC_HIP_EINVAL, "the shards' generators are out of step");
+    }
+    // BP_DEC with the frame chain on is sequential by definition (decoders.cpp:1742-1762): shard 0 decodes every frame
+    const bool chained = decode && c0->decoder_id == LDPC_HIP_BP_DEC && c0->bp_chain;
+    long long per_round = mt_frames_per_round(c0);
+    if (per_round > (1 << 16)) per_round = 1 << 16;
+    struct Seg { long long first, count, off; };
+    std::vector<std::vector<Seg>> segs((size_t)n);
+    std::vector<long long> used((size_t)n, 0);   // record slots taken per shard
+    if (decode) {
+        const int rc = for_each_shard(m, [&](int i) -> int {   // record buffers: at most ceil(B / n) + one round's share per shard ... B bounds it
+            ldpc_hip_ctx *c = m->shard[(size_t)i];
+            if (int r = set_device(c)) return r;
+            const long long cap = chained ? (i == 0 ? B : 0) : (B / n + per_round / n + 2 * ((B + per_round - 1) / per_round) + 2);
+            ldpc_mt::DeviceState &ms = c->mt;
+            if (cap > ms.cap_rec) {
+                if (ms.d_info) (void)hipFree(ms.d_info);
+                if (ms.d_iters) (void)hipFree(ms.d_iters);
+                ms.d_info = nullptr; ms.d_iters = nullptr; ms.cap_rec = 0;
+                HIP_TRY(hipMalloc(&ms.d_info, sizeof(int32_t) * (size_t)cap));
+                HIP_TRY(hipMalloc(&ms.d_iters, sizeof(int32_t) * (size_t)cap));
+                ms.cap_rec = cap;
+            }
+            HIP_TRY(hipMemsetAsync(c->w_counters, 0, sizeof(unsigned long long) * 8, m->stream[(size_t)i]));
+            return 0;
+        });
+        if (rc) return rc;
+    }
+    long long done = 0;
+    int stalled = 0;
+    std::vector<long long> part((size_t)n + 1);
+    while (done < B) {
+        const long long fr = B - done < per_round ? B - done : per_round;
+        for (int i = 0; i <= n; ++i) part[(size_t)i] = chained ? (i == 0 ? 0 : fr) : fr * i / n;
+        if (decode) {
+            const int rc = for_each_shard(m, [&](int i) -> int {
+                const long long mine = part[(size_t)i + 1] - part[(size_t)i];
+                if (mine <= 0) return 0;
+                if (int r = set_device(m->shard[(size_t)i])) return r;
+                return ensure_workspace(m->shard[(size_t)i], mine, false);
+            });
+            if (rc) return rc;
+        }
+        const long long first = c0->mt.frames_taken;
+        long long fdone = 0;
+        if (int rc = multi_mt_round(m, snr_db, modulation_type, punctured_blocks, fr, part, decode, &fdone)) return rc;
+        if (decode && fdone > 0) {
+            const int rc = for_each_shard(m, [&](int i) -> int {
+                ldpc_hip_ctx *c = m->shard[(size_t)i];
+                const long long r_lo = part[(size_t)i], r_hi = part[(size_t)i + 1] < fdone ? part[(size_t)i + 1] : fdone;
+                if (r_lo >= r_hi) return 0;
+                if (int r = set_device(c)) return r;
+                hipStream_t st = m->stream[(size_t)i];
+                const long long off = used[(size_t)i], rows = r_hi - r_lo;
+                if (off + rows > c->mt.cap_rec) return fail(LDPC_HIP_EHIP, "exact replay: record buffer of shard %d too small", i);
+                int32_t *it = c->mt.d_iters + off;
+                if (int r = ldpc_hip_decode_dev(c, c->w_llr, rows, maxiter, alpha, c->w_hard, it, nullptr, st)) return r;
+                if (int r = ldpc_hip_count_errors_cw_dev(c, c->w_hard, it, first + r_lo, rows, c->mt.d_info + off, c->w_counters, st)) return r;
+                segs[(size_t)i].push_back(Seg{done + r_lo, rows, off});
+                used[(size_t)i] += rows;   // (the next round's emit pass follows on the same stream: the workspace rows are safe)
+                return 0;
+            });
+            if (rc) return rc;
+        }
+        done += fdone;
+        stalled = fdone == 0 ? stalled + 1 : 0;
+        if (stalled >= 2) return fail(LDPC_HIP_EHIP, "the exact-replay generator made no progress (frame of %d samples)", c0->N);
+    }
+    if (decode) {
+        const int rc = for_each_shard(m, [&](int i) -> int {
+            ldpc_hip_ctx *c = m->shard[(size_t)i];
+            if (int r = set_device(c)) return r;
+            for (const Seg &sg : segs[(size_t)i]) {
+                HIP_TRY(hipMemcpy(frame_info + sg.first, c->mt.d_info + sg.off, sizeof(int32_t) * (size_t)sg.count, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(iters + sg.first, c->mt.d_iters + sg.off, sizeof(int32_t) * (size_t)sg.count, hipMemcpyDeviceToHost));
+            }
+            return 0;
+        });
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
 int ldpc_hip_mt_set_state_multi(ldpc_hip_multi *m, const uint32_t state[624], int pos) {
     if (!m) return fail(LDPC_HIP_EINVAL, "null multi context");
     for (ldpc_hip_ctx *c : m->shard) if (int rc = ldpc_hip_mt_set_state(c, state, pos)) return rc;
@@ -493,26 +729,19 @@ int ldpc_hip_mt_set_frame_index_multi(ldpc_hip_multi *m, long long frames_taken)
 
 int ldpc_hip_mt_advance_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, long long B) {
     if (!m || B < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_advance_multi: bad argument");
-    return for_each_shard(m, [&](int i) -> int {
-        ldpc_hip_ctx *c = m->shard[(size_t)i];
-        if (int r = set_device(c)) return r;
-        return mt_llr_rows(c, snr_db, modulation_type, punctured_blocks, B, 0, 0, nullptr, m->stream[(size_t)i]);
-    });
+    return multi_mt_frames(m, snr_db, modulation_type, punctured_blocks, 1, 0.8, B, false, nullptr, nullptr);
 }
 
 int ldpc_hip_mt_frames_multi(ldpc_hip_multi *m, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha,
                              long long B, int32_t *frame_info, int32_t *iters) {
     if (!m || B < 0 || !frame_info || !iters) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_frames_multi: bad argument");
-    const int n = (int)m->shard.size();
-    // BP_DEC with the frame chain on is sequential by definition (decoders.cpp:1742-1762): shard 0 decodes the whole batch
-    const bool chained = m->shard[0]->decoder_id == LDPC_HIP_BP_DEC && m->shard[0]->bp_chain;
-    return for_each_shard(m, [&](int i) -> int {
-        ldpc_hip_ctx *c = m->shard[(size_t)i];
-        if (int r = set_device(c)) return r;
-        long long lo = B * i / n, hi = B * (i + 1) / n;
-        if (chained) { lo = i == 0 ? 0 : B; hi = B; }
-        return mt_frames_slice(c, snr_db, modulation_type, punctured_blocks, maxiter, alpha, B, lo, hi, frame_info + lo, iters + lo, m->stream[(size_t)i]);
-    });
+    return multi_mt_frames(m, snr_db, modulation_type, punctured_blocks, maxiter, alpha, B, true, frame_info, iters);
+}
+
+/* rounds that ran sharded / that fell back to every shard generating the whole tape, since the multi context was opened */
+void ldpc_hip_multi_mt_stats(const ldpc_hip_multi *m, long long *sharded_rounds, long long *fallback_rounds) {
+    if (sharded_rounds) *sharded_rounds = m ? m->mt_sharded_rounds : 0;
+    if (fallback_rounds) *fallback_rounds = m ? m->mt_fallbacks : 0;
 }
 
 }  // extern "C"

@@ -50,7 +50,13 @@ struct SpecArgs {
     const double *ims_coef;   // [B] sqrt(N / sum y^2) per frame, from ims_coef_kernel (the sum is sequential: its rounding is part of the result)
     double ims_thr;
     int ims_max_quant, ims_max_data, ims_ialpha;
-    long long nframes;        // ms_small_body only: frames in the batch (several frames share a workgroup, the last one may be partly empty)
+    long long nframes;        // frames in the batch (ms_small_body: several frames share a workgroup, the last one may be partly empty;
+                              // ms_m64_body: where its frame queue ends)
+    unsigned *queue;          // ms_m64_body only, or null: frame queue of a PERSISTENT launch.  The grid is one resident wave per
+                              // slot of the chip instead of one workgroup per frame; wave b decodes frame b, then frames
+                              // gridDim.x + atomicAdd(queue, 1) until nframes is reached (the host zeroes *queue before the launch).
+                              // Frames converge after different numbers of iterations: pulling the next frame the moment a wave is
+                              // free costs one atomic per frame and saves a workgroup launch per frame.
 };
 
 template <int I> struct IC { static constexpr int value = I; };
@@ -353,7 +359,7 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
     const int lane = threadIdx.x;
     const u32 n8 = (u32)lane * 8u;
     const double alpha = a.alpha;
-    const long long fr = blockIdx.x;  // one wave per frame
+    long long fr = blockIdx.x;  // one wave per frame; with a.queue the wave goes on to further frames (uniform: an SGPR pair)
 
     // LDS byte offset (inside a block column) of variable (lane + shift) mod 64.  `base` is an opaque per-row copy of
     // n8: it keeps the compiler from hoisting/CSE-ing the ~40 distinct rotated addresses out of the iteration loop
@@ -364,6 +370,7 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
         else return (base + 8u * (u32)c) & 511u;
     };
 
+  while (fr < a.nframes) {   // one pass without a queue
     const double *const yrow = a.llr + fr * N + lane;  // this frame's channel LLRs, variable (k, lane) at yrow[64 k]
 
     double m1[RH], m2[RH];
@@ -478,6 +485,11 @@ __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
             a.soft_out[fr * N + k * 64 + lane] = *reinterpret_cast<const double *>(ldsb + n8 + k * 512);
         });
     }
+    if (!a.queue) break;
+    u32 ticket = 0;
+    if (lane == 0) ticket = atomicAdd(a.queue, 1u);
+    fr = (long long)gridDim.x + (long long)(u32)__builtin_amdgcn_readfirstlane((int)ticket);   // every wave ends here: fr >= nframes
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

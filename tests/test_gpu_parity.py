@@ -898,24 +898,28 @@ import os, sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
 import numpy as np, torch
 import ldpc_lib_amd as L
-from ldpc_testlib import load_base_matrix, relift, awgn_llr, TASP_DEC, MS_DEC
+from ldpc_testlib import load_base_matrix, relift, awgn_llr, BP_DEC
 mode = sys.argv[1]
 H = relift(load_base_matrix(), 64).copy()
 H[H > 0] = (H[H > 0] * 7 + 3 + len(mode)) % 64
-dec = L.LdpcHip(TASP_DEC if mode == "decode" else MS_DEC, H, 64)
-assert "hiprtc" not in dec.kernel_name, dec.kernel_name      # the instance is still being compiled
+torch.zeros(1).cuda()                                   # the HIP context exists before the open, so the open itself is quick
+dec = L.LdpcHip(BP_DEC, H, 64)                          # bp_body: the longest compile of all bodies (tens of seconds)
 if mode == "decode":
     dec.decode(torch.from_numpy(awgn_llr(H, 64, 2.0, 1, 16)).cuda(), 15)
     torch.cuda.synchronize()
+inflight = "hiprtc" not in dec.kernel_name              # the instance is still being compiled
 if mode != "leak":
     dec.close()
-print("leaving", mode, flush=True)
+print("leaving", mode, "inflight" if inflight else "done", flush=True)
 sys.exit(7)
 """
+    seen_inflight = 0
     for mode in ("open", "decode", "leak"):
         env = dict(os.environ, LDPC_HIP_JIT="async", LDPC_HIP_CACHE_DIR=str(tmp_path / mode))
         p = subprocess.run([sys.executable, "-c", script.format(root=root), mode], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 7 and "leaving " + mode in p.stdout, (mode, p.returncode, p.stdout[-500:], p.stderr[-1500:])
+        seen_inflight += "inflight" in p.stdout
+    assert seen_inflight >= 2, "the compile was never in flight at exit: the test did not exercise what it is for"
 
 
 def test_contexts_closed_before_their_compile_are_dropped(L, torch, tmp_path, monkeypatch):

@@ -388,3 +388,90 @@ def test_c_example_replays_the_headline_run(L, torch, tmp_path):
     res = _oracle_sim(relift(load_base_matrix(), 64), 64, MS_DEC, 2.0, 50, 10**9, 4000, 1.0, 1)
     # the state the example reports continues upstream's stream: its next word is the sequential loop's next word
     assert int(out[out.index("undetected") + 1]) == res.nue
+
+
+# ---- the generator shared out over the shards of a multi context (csrc/ldpc_multi.hpp: multi_mt_round) ---------------------------------
+def _after_codeword_draws(H, M, seed):
+    key, pos = seeded_state(seed)
+    bg = np.random.MT19937()
+    s = bg.state
+    s["state"]["key"] = key; s["state"]["pos"] = pos
+    bg.state = s
+    bg.random_raw((H.shape[1] - H.shape[0]) * M)
+    return bg.state["state"]["key"].astype(np.uint32), int(bg.state["state"]["pos"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("forced", ["1", None])
+@pytest.mark.parametrize("dec_id,M,snr,frames,splits", [(MS_DEC, 64, 2.0, 9000, (4000, 5000)), (LMS_DEC, 126, 1.7, 2500, (2500,)), (MS_DEC, 1, 4.0, 70000, (69000, 1000)),
+                                                         (BP_DEC, 64, 2.0, 700, (300, 400))])
+def test_sharded_generation_gives_the_single_context_records_and_state(L, torch, monkeypatch, dec_id, M, snr, frames, splits, forced):
+    """ldpc_hip_mt_frames_multi with the word tape shared out (every shard makes ~1/n of the sub-streams, the accepted-attempt counts
+    are exchanged through the host): per-frame records in global order and the generator state afterwards equal the single-context
+    run for n = 1, 2, 3, 8 logical shards, in several calls; with LDPC_HIP_MT_SHARDED=1 every round must have run sharded and none
+    may have fallen back to the whole tape.  BP_DEC (frame chain on) decodes on shard 0 while the generation is still shared."""
+    if forced:
+        monkeypatch.setenv("LDPC_HIP_MT_SHARDED", forced)
+    H = relift(load_base_matrix(), M)
+    key, pos = _after_codeword_draws(H, M, 11)
+    maxit = 20
+    with L.LdpcHip(dec_id, H, M) as dec:
+        dec.mt_set_state(key, pos)
+        parts = [dec.mt_frames(snr, maxit, b) for b in splits]
+        want_info, want_it = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+        want_state = dec.mt_get_state()
+        assert dec.mt_frame_index() == frames
+    assert (want_info != 0).any()
+    for n in (1, 2, 3, 8):
+        with L.LdpcHipMulti(dec_id, H, M, [0] * n) as m:
+            m.mt_set_state(key, pos)
+            parts = [m.mt_frames(snr, maxit, b) for b in splits]
+            info, its = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+            st = m.mt_get_state()
+            sharded, fallback = m.mt_stats()
+            assert np.array_equal(info, want_info) and np.array_equal(its, want_it), n
+            assert np.array_equal(st[0], want_state[0]) and st[1] == want_state[1], n
+            if forced and n > 1:
+                assert sharded >= len(splits) and fallback == 0, (n, sharded, fallback)
+            if n == 1:
+                assert sharded == 0
+
+
+@pytest.mark.gpu
+def test_sharded_generation_with_the_whole_chain_and_roll_forward(L, torch, monkeypatch):
+    """QAM4 + block interleaver + two punctured blocks + several real codewords through the shared-out generator; then a roll-back
+    as the harness does it after an early stop (set_state + frame index + advance): same records for every shard count."""
+    monkeypatch.setenv("LDPC_HIP_MT_SHARDED", "1")
+    M = 64
+    H = relift(load_base_matrix(), M)
+    key, pos = _after_codeword_draws(H, M, 5)
+    from ldpc_lib_amd.binding import encode
+    rng = np.random.RandomState(3)
+    cws = np.stack([encode(H, M, rng.randint(0, 2, size=(H.shape[1] - H.shape[0]) * M).astype(np.uint8)) for _ in range(3)])
+
+    def run(obj):
+        obj.set_interleaver(3, 64, 1)
+        obj.set_codewords(cws)
+        obj.mt_set_state(key, pos)
+        a = obj.mt_frames(1.6, 30, 3000, modulation=1, punctured_blocks=2)
+        snap = obj.mt_get_state()
+        b = obj.mt_frames(1.6, 30, 2000, modulation=1, punctured_blocks=2)
+        obj.mt_set_state(*snap)                                        # stopped 700 frames into the second call
+        obj.mt_set_frame_index(3000)
+        if hasattr(obj, "mt_advance"):
+            obj.mt_advance(1.6, 700, modulation=1, punctured_blocks=2)
+        else:
+            obj.mt_llr(1.6, 700, modulation=1, punctured_blocks=2, skip=True)
+        c = obj.mt_frames(1.6, 30, 500, modulation=1, punctured_blocks=2)
+        return a, b, c, obj.mt_get_state()
+
+    with L.LdpcHip(LMS_DEC, H, M) as dec:
+        want = run(dec)
+    assert np.array_equal(want[1][0][700:1200], want[2][0])            # frames 3700..4199 either way
+    for n in (2, 3, 8):
+        with L.LdpcHipMulti(LMS_DEC, H, M, [0] * n) as m:
+            got = run(m)
+            for k in range(3):
+                assert np.array_equal(got[k][0], want[k][0]) and np.array_equal(got[k][1], want[k][1]), (n, k)
+            assert np.array_equal(got[3][0], want[3][0]) and got[3][1] == want[3][1]
+            assert m.mt_stats()[1] == 0
