@@ -81,6 +81,10 @@ EXTRA_CONFIGS = [
          what="(2048,1024) integer min-sum 50 it (SURVEY 8 f1)"),
     dict(key="f2_tasp_m126", dec=DEC_TASP, M=126, frames=16384, maxiter=15, oper_snr=1.7, modulation=0, formula=None,
          what="(4032,2016) M=126 TDMP sum-product 15 it, the shipped search scenario (SURVEY 8 f2)"),
+    dict(key="f2_bp_m64", dec=DEC_BP, M=64, frames=8192, maxiter=50, oper_snr=2.0, modulation=0, formula=None,
+         what="(2048,1024) Gallager BP (log domain) 50 it, frames chained through upstream's uncleared syndrome (SURVEY 8 f2)"),
+    dict(key="f2_asp_m64", dec=DEC_ASP, M=64, frames=16384, maxiter=50, oper_snr=2.0, modulation=0, formula=None,
+         what="(2048,1024) flooding sum-product in the probability domain 50 it (SURVEY 8 f2)"),
 ]
 
 
@@ -455,43 +459,56 @@ def main():
 
     pmc, pmc_why = load_pmc()
 
-    def timed(dec, B, snr, steps, warmup, maxiter, modulation=0):
+    def timed(dec, B, snr, steps, warmup, maxiter, modulation=0, dec_b=None):
         """W warm-up + K timed steps (decode + count [+ all-reduce]) over batches resident in HBM; returns wall seconds (max over
-        ranks), the counter totals and the decode kernel's HIP-event time."""
+        ranks), the counter totals and the decode kernel's HIP-event time.  With a second context `dec_b` consecutive steps alternate
+        between two HIP streams (one context each), so that two batches are in flight: where frames leave early (operating point) the
+        slots the last long-running frames of one batch leave idle are taken by the next batch."""
         nb = min(max(steps, 1), 8)
         if B * dec.N * 8 * nb > 12e9:
             nb = max(1, int(12e9 // (B * dec.N * 8)))
         # distinct frames per step and per rank: global frame index = (step*world + rank)*B + i
         batches = [dec.awgn_llr(snr, seed=1, first_frame=(s * world + rank) * B, B=B, modulation=modulation) for s in range(nb)]
-        hard = torch.empty((B, dec.hard_words), dtype=torch.int32, device=dev)
-        iters = torch.empty((B,), dtype=torch.int32, device=dev)
-        cnt = torch.zeros(5, dtype=torch.int64, device=dev)
-        tot = torch.zeros(5, dtype=torch.int64, device=dev)
+        lanes = []
+        for d in ([dec] if dec_b is None else [dec, dec_b]):
+            lanes.append({"dec": d, "stream": torch.cuda.current_stream(dev) if dec_b is None else torch.cuda.Stream(dev),
+                          "hard": torch.empty((B, dec.hard_words), dtype=torch.int32, device=dev),
+                          "iters": torch.empty((B,), dtype=torch.int32, device=dev),
+                          "cnt": torch.zeros(5, dtype=torch.int64, device=dev), "tot": torch.zeros(5, dtype=torch.int64, device=dev)})
+        torch.cuda.synchronize(dev)
 
-        def step(llr):
-            dec.decode(llr, maxiter, alpha=ALPHA, out=(hard, iters, None))
-            cnt.zero_()
-            dec.count_errors(hard, iters, counters=cnt)
-            if world > 1:
-                all_reduce(cnt)  # 40-byte message: {nse, nde, nue, frames, sum|iters|}
-            tot.add_(cnt)
+        def step(s):
+            ln = lanes[s % len(lanes)]
+            with torch.cuda.stream(ln["stream"]):
+                ln["dec"].decode(batches[s % nb], maxiter, alpha=ALPHA, out=(ln["hard"], ln["iters"], None))
+                ln["cnt"].zero_()
+                ln["dec"].count_errors(ln["hard"], ln["iters"], counters=ln["cnt"])
+                if world > 1:
+                    all_reduce(ln["cnt"])  # 40-byte message: {nse, nde, nue, frames, sum|iters|}
+                ln["tot"].add_(ln["cnt"])
 
         for s in range(warmup):
-            step(batches[s % nb])
-        tot.zero_()
-        dec.profile(True)
-        dec.profile_read(reset=True)
+            step(s)
+        barrier()
+        for ln in lanes:
+            ln["tot"].zero_()
+            ln["dec"].profile(True)
+            ln["dec"].profile_read(reset=True)
         barrier()
         t0 = time.perf_counter()
         for s in range(steps):
-            step(batches[s % nb])
+            step(s)
         barrier()
         el = time.perf_counter() - t0
-        kms, klaunch = dec.profile_read(reset=True)
-        dec.profile(False)
+        kms, klaunch = 0.0, 0
+        for ln in lanes:
+            k, l = ln["dec"].profile_read(reset=True)
+            kms, klaunch = kms + k, klaunch + l
+            ln["dec"].profile(False)
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         if world > 1:
             all_reduce(t, op=dist.ReduceOp.MAX)
+        tot = sum(ln["tot"] for ln in lanes)
         del batches
         return float(t.item()), tot.cpu().tolist(), kms, klaunch
 
@@ -524,10 +541,20 @@ def main():
                                "(fp64 + half-rate VOP3 / compare / select), see valu_issue / lds / hbm_physical")
 
     if not args.no_extras:
-        el2, tot2, kms2, kl2 = timed(dec, B, OPER_SNR, max(4, args.steps // 2), 1, MAXITER)
+        osteps = max(4, args.steps // 2)
+        el2, tot2, kms2, kl2 = timed(dec, B, OPER_SNR, osteps, 1, MAXITER)
+        with ldpc_lib_amd.LdpcHip(DEC_MS, H, M, device=local) as dec_b:   # the same workload with two batches in flight on two streams
+            el3, tot3, kms3, kl3 = timed(dec, B, OPER_SNR, 2 * osteps, 2, MAXITER, dec_b=dec_b)
+        worst_fi = sum_iters_rank * world / el   # frame-iterations/s with no early exit
         out["operating_point"] = {
-            "ebn0_db": OPER_SNR, "value": tot2[3] / el2, "unit": "frames/s", "fer": tot2[1] / tot2[3],
-            "ber": tot2[0] / tot2[3] / (N - R), "mean_iters_per_frame": tot2[4] / tot2[3],
+            "ebn0_db": OPER_SNR, "value": tot3[3] / el3, "unit": "frames/s", "fer": tot3[1] / tot3[3],
+            "ber": tot3[0] / tot3[3] / (N - R), "mean_iters_per_frame": tot3[4] / tot3[3],
+            "how": "two batches in flight on two HIP streams (one context each): the slots that the last long-running frames of a "
+                   "batch leave idle are taken by the next batch; persistent waves pull frames from a queue (SpecArgs::queue)",
+            "frame_iterations_per_s": tot3[4] / el3, "fraction_of_worst_case_frame_iterations_per_s": (tot3[4] / el3) / worst_fi,
+            "one_batch_at_a_time": {"value": tot2[3] / el2, "frame_iterations_per_s": tot2[4] / el2,
+                                    "fraction_of_worst_case_frame_iterations_per_s": (tot2[4] / el2) / worst_fi,
+                                    "kernel_ms_avg": kms2 / max(kl2, 1)},
             "roofline_achieved_GBs": (tot2[4] / world * bytes_iter) / (kms2 / 1e3) / 1e9,
         }
         sweep = []

@@ -695,6 +695,7 @@ int multi_mt_frames(ldpc_hip_multi *m, double snr_db, int modulation_type, int p
         const int rc = for_each_shard(m, [&](int i) -> int {
             ldpc_hip_ctx *c = m->shard[(size_t)i];
             if (int r = set_device(c)) return r;
+            HIP_TRY(hipStreamSynchronize(m->stream[(size_t)i]));   // the shard's streams do not synchronise with the copies below
             for (const Seg &sg : segs[(size_t)i]) {
                 HIP_TRY(hipMemcpy(frame_info + sg.first, c->mt.d_info + sg.off, sizeof(int32_t) * (size_t)sg.count, hipMemcpyDeviceToHost));
                 HIP_TRY(hipMemcpy(iters + sg.first, c->mt.d_iters + sg.off, sizeof(int32_t) * (size_t)sg.count, hipMemcpyDeviceToHost));
