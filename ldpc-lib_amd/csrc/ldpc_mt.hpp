@@ -42,6 +42,7 @@ constexpr int kLevels = 12;                           // jump polynomials for 2^
 constexpr int kMaxStreams = 1024;                     // streams per round
 constexpr int kDegree = 19937;
 constexpr int kMaxBits = 10752;                        // set coefficients per polynomial: 19937 / 2 +- a few hundred
+constexpr int kBitsPad = 192;                          // readable entries behind the last table (the jump kernel requests exponents ahead)
 constexpr int kSeqWords = 20608;                      // >= 19937 + 624 + 31: the LDS image of one jump (82 432 bytes)
 constexpr unsigned long long kRoundItems = 1ull << 27;   // samples per generation round (5.1 words each: <= 2.8 GB of words)
 
@@ -218,13 +219,23 @@ struct JumpArgs {
     int src_first, dst_first;
 };
 
-__global__ void __launch_bounds__(640) mt_jump_kernel(const JumpArgs a) {
+constexpr int kJumpThreads = 640;   // ten waves: thread t < 624 makes state word t
+
+// Per set coefficient p, state word k gains x[k + p]: an LDS read at a uniform offset per thread.  What bounds the loop is the LDS
+// (about six cycles per wave-wide 32-bit read on this part: ~60 cycles per coefficient for the ten waves), so the exponents must
+// not add latency in front of the reads.  As scalar loads they share the LDS's counter (lgkmcnt) and cannot be requested ahead;
+// they therefore come through the VECTOR memory path (its own counter) from an address the compiler cannot see to be uniform, 64
+// at a time as sixteen 16-byte loads with progressive waits -- the table is padded, so reading ahead of a part's end is harmless.
+// Measured per 256 full jumps: 276 us with one s_load per eight exponents in front of every eight reads (round 2), 240 us this
+// way; 305 us with three words per thread and v_readlane broadcasts (four waves: too few to cover the LDS latency).
+__global__ void __launch_bounds__(kJumpThreads) mt_jump_kernel(const JumpArgs a) {
     extern __shared__ uint32_t mt_x[];   // kSeqWords
     const int tid = threadIdx.x;
     const int jump = blockIdx.x / a.parts, part = blockIdx.x - jump * a.parts;
     const uint32_t *src = a.states + (size_t)(a.src_first + jump) * MTN;
     uint32_t *dst = a.states + (size_t)(a.dst_first + jump) * MTN;
-    const int j_lo = (int)((long long)a.nbits * part / a.parts), j_hi = (int)((long long)a.nbits * (part + 1) / a.parts);
+    const int j_lo = (int)((long long)a.nbits * part / a.parts) & ~3;   // multiples of 4: the exponent loads are 16 bytes wide
+    const int j_hi = part + 1 == a.parts ? a.nbits : (int)((long long)a.nbits * (part + 1) / a.parts) & ~3;
     if (j_lo >= j_hi) return;
     const int need = (int)a.bits[j_hi - 1] + MTN;   // words x[0 .. need) cover this part
     if (tid < MTN) mt_x[tid] = src[tid];
@@ -237,13 +248,27 @@ __global__ void __launch_bounds__(640) mt_jump_kernel(const JumpArgs a) {
     if (tid < MTN) {
         uint32_t acc = 0;
         const uint32_t *xp = mt_x + tid;
-        int j = j_lo;
-        for (; j + 8 <= j_hi; j += 8) {   // the exponents are uniform: scalar loads
-            const uint32_t p0 = a.bits[j], p1 = a.bits[j + 1], p2 = a.bits[j + 2], p3 = a.bits[j + 3];
-            const uint32_t p4 = a.bits[j + 4], p5 = a.bits[j + 5], p6 = a.bits[j + 6], p7 = a.bits[j + 7];
-            acc ^= xp[p0] ^ xp[p1] ^ xp[p2] ^ xp[p3] ^ xp[p4] ^ xp[p5] ^ xp[p6] ^ xp[p7];
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));
+        const uint4 *bq = reinterpret_cast<const uint4 *>(a.bits + j_lo + opaque);   // j_lo is a multiple of 4: 16-byte aligned
+        const int n = j_hi - j_lo, nb32 = n >> 5;
+        uint4 e[8], f[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = bq[u];
+        for (int b = 0; b < nb32; ++b) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) f[u] = bq[(b + 1) * 8 + u];
+            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                t0 ^= xp[e[u].x]; t1 ^= xp[e[u].y]; t2 ^= xp[e[u].z]; t3 ^= xp[e[u].w];
+            }
+            acc ^= (t0 ^ t1) ^ (t2 ^ t3);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) e[u] = f[u];
         }
-        for (; j < j_hi; ++j) acc ^= xp[a.bits[j]];
+        const uint32_t *bp = a.bits + j_lo;
+        for (int j = nb32 << 5; j < n; ++j) acc ^= xp[bp[j]];
         if (a.parts == 1) dst[tid] = acc;
         else atomicXor(&dst[tid], acc);
     }
@@ -259,67 +284,115 @@ struct GenArgs {
     long long words;          // tape words wanted behind the first 624 (a multiple of 64): streams stop there
 };
 
-// Wave-level ordering point for LDS traffic between lanes of ONE wave: the LDS executes a wave's operations in issue order, so only
-// the compiler has to be kept from moving accesses across it.
-__device__ __forceinline__ void mt_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+// The twist of the recurrence: x[i+624] = x[i+397] ^ mt_twist(x[i], x[i+1]).
+__device__ __forceinline__ uint32_t mt_twist(uint32_t x0, uint32_t x1) {
+    const uint32_t y = (x0 & 0x80000000u) | (x1 & 0x7fffffffu);
+    return (y >> 1) ^ ((x1 & 1u) ? 0x9908b0dfu : 0u);
 }
 
-// NSUB sub-steps of 64 words starting at word LO of the 624-word block, in place: every operand is read before any word of the
-// group is written (x[i+1] and x[i+397] of the old block, x[i-227] of the new one, written by an earlier group).
-template <int LO, int NSUB>
-__device__ __forceinline__ void mt_group(uint32_t *x, uint32_t *out_blk, const int lane, const uint32_t remaining) {
-    uint32_t x0[NSUB], x1[NSUB], xm[NSUB];
-#pragma unroll
-    for (int u = 0; u < NSUB; ++u) {
-        const int lo = LO + 64 * u, i = lo + lane;
-        if (lo + 64 <= MTN || lane < MTN - lo) {
-            x0[u] = x[i];
-            x1[u] = x[(lo + 64 > MTN && i == MTN - 1) ? 0 : i + 1];                    // x[624] is word 0 of the new block
-            xm[u] = x[lo + 63 < 227 ? i + 397 : lo >= 227 ? i - 227 : i < 227 ? i + 397 : i - 227];
-        }
-    }
-    mt_wave_sync();
-#pragma unroll
-    for (int u = 0; u < NSUB; ++u) {
-        const int lo = LO + 64 * u, i = lo + lane;
-        if (lo + 64 <= MTN || lane < MTN - lo) {
-            const uint32_t v = mt_next(x0[u], x1[u], xm[u]);
-            x[i] = v;
-            if ((uint32_t)i < remaining) out_blk[i] = v;   // per lane: a stream may end anywhere inside its last block (624 = 9 * 64 + 48)
-        }
-    }
-    mt_wave_sync();
+// One WORKGROUP per stream, a whole 624-word block per step.  The textbook update walks a block in three dependent stretches (a new
+// word needs the new word 227 places back); substituting the recurrence into itself removes that dependence inside a block:
+// with Tv[i] = twist(x[i], x[i+1]) of the OLD block,
+//     new[i] = old[i+397] ^ Tv[i]                                   i <  227
+//            = old[i+170] ^ Tv[i-227] ^ Tv[i]                       227 <= i < 454      (x[i+397] = new[i-227])
+//            = old[i-57]  ^ Tv[i-454] ^ Tv[i-227] ^ Tv[i]           454 <= i < 624      (twice)
+// (Tv[623] needs x[624] = new[0] = old[397] ^ Tv[0], which the thread of word 623 forms itself.)  So a block costs two barrier
+// steps -- every thread twists its own words, then combines three or four LDS values -- instead of ten dependent sub-steps of one
+// wave, and a stream of 2^20 words is 1681 steps long instead of ~17 000.  Same words, bit for bit.
+constexpr int kGenThreads = 320;   // five waves, two words per thread (624 = 2 * 312)
+
+// workgroup barrier that orders LDS traffic only: the words stored to global memory in the step before must not be waited for
+// (__syncthreads() waits for every outstanding store, ~1 us per block here)
+__device__ __forceinline__ void mt_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-__global__ void __launch_bounds__(256) mt_generate_kernel(const GenArgs a) {
-    __shared__ uint32_t blk_all[4][640];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + wv;
-    if (j >= a.S) return;    // no workgroup barrier below: a wave is on its own
-    uint32_t *x = blk_all[wv];
+// one block: x (old, LDS) -> nx (new, LDS) and out (HBM); xr = the thread's own words of the old block on entry, of the new on exit.
+// Everything address-like is a function of (thread, k) only, i.e. invariant over the block loop; no branch depends on data.
+template <int T>
+__device__ __forceinline__ void mt_block(const uint32_t *x, uint32_t *nx, uint32_t *tv, const uint32_t *zero, uint32_t (&xr)[(MTN + T - 1) / T],
+                                         uint32_t *ob, const uint32_t remaining, const int tid) {
+    constexpr int W = (MTN + T - 1) / T, KS = (MTN - 1) / T;   // KS: the k of word 623
+    // ---- step 1: every thread twists its own words with their right-hand neighbours.  All loads first, then the arithmetic: one
+    // LDS round trip per step, not one per word.
+    uint32_t b[W], tw[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const int i = tid + k * T;
+        b[k] = x[i < MTN ? i + 1 : 0];
+    }
+    const uint32_t s0 = x[0], s1 = x[1], s397 = x[397];   // x[624] is the new word 0 = old[397] ^ twist(old[0], old[1])
+    __builtin_amdgcn_sched_barrier(0);
+    b[KS] = tid + KS * T == MTN - 1 ? (s397 ^ mt_twist(s0, s1)) : b[KS];
+#pragma unroll
+    for (int k = 0; k < W; ++k) tw[k] = mt_twist(xr[k], b[k]);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const int i = tid + k * T;
+        if (i < 397) tv[i] = tw[k];   // the twists other words need: tv[i - 227] (i - 227 <= 396), tv[i - 454]
+    }
+    mt_lds_barrier();
+    // ---- step 2: combine
+    uint32_t o[W], q1[W], q2[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const int i = tid + k * T, ic = i < MTN ? i : 0;
+        const int src = ic + 397 - (ic >= 227 ? 227 : 0) - (ic >= 454 ? 227 : 0);
+        const uint32_t *p1 = ic >= 227 ? tv + (ic - 227) : zero, *p2 = ic >= 454 ? tv + (ic - 454) : zero;
+        o[k] = x[src]; q1[k] = *p1; q2[k] = *p2;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < W; ++k) xr[k] = (o[k] ^ tw[k]) ^ (q1[k] ^ q2[k]);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const int i = tid + k * T;
+        if (i < MTN) {
+            nx[i] = xr[k];
+            if ((uint32_t)i < remaining) ob[i] = xr[k];   // per word: a stream may end anywhere inside its last block
+        }
+    }
+    mt_lds_barrier();
+}
+
+template <int T>
+__device__ __forceinline__ void mt_generate_body(const GenArgs &a) {
+    constexpr int W = (MTN + T - 1) / T;
+    __shared__ uint32_t xb[2][MTN + 16];
+    __shared__ uint32_t tv[400];
+    __shared__ uint32_t zero[4];
+    const int tid = threadIdx.x;
+    const int j = blockIdx.x;
     const uint32_t *st = a.states + (size_t)j * MTN;
     const long long gj = a.first + j;   // the stream's index on the tape
-    for (int i = lane; i < MTN; i += 64) {
-        const uint32_t v = st[i];
-        x[i] = v;
-        if (gj == 0) a.xraw[i] = v;
+    uint32_t xr[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const int i = tid + k * T;
+        xr[k] = 0;
+        if (i < MTN) {
+            xr[k] = st[i];
+            xb[0][i] = xr[k];
+            if (gj == 0) a.xraw[i] = xr[k];
+        }
     }
-    mt_wave_sync();
+    if (tid < 4) zero[tid] = 0u;
+    if (tid < 16) { xb[0][MTN + tid] = 0u; xb[1][MTN + tid] = 0u; }
+    __syncthreads();
     const long long stride = 1ll << a.log2_stride;
     uint32_t *out = a.xraw + (size_t)j * (size_t)stride + MTN;   // the stream's words [0, stride)
     const long long left = a.words - gj * stride;
     const uint32_t nwords = left >= stride ? (uint32_t)stride : left > 0 ? (uint32_t)left : 0u;   // a short round stops early
-    for (uint32_t w0 = 0; w0 < nwords; w0 += MTN) {   // the classic in-place block update, 3 + 3 + 3 + 1 sub-steps
-        const uint32_t remaining = nwords - w0;
-        uint32_t *ob = out + w0;
-        mt_group<0, 3>(x, ob, lane, remaining);
-        mt_group<192, 3>(x, ob, lane, remaining);
-        mt_group<384, 3>(x, ob, lane, remaining);
-        mt_group<576, 1>(x, ob, lane, remaining);
+    for (uint32_t w0 = 0; w0 < nwords; w0 += 2 * MTN) {   // two blocks per trip: the buffers' roles are fixed inside it
+        mt_block<T>(xb[0], xb[1], tv, zero, xr, out + w0, nwords - w0, tid);
+        if (w0 + MTN >= nwords) break;
+        mt_block<T>(xb[1], xb[0], tv, zero, xr, out + w0 + MTN, nwords - w0 - MTN, tid);
     }
 }
+
+__global__ void __launch_bounds__(kGenThreads) mt_generate_kernel(const GenArgs a) { mt_generate_body<kGenThreads>(a); }
 
 // ---- device: the polar method over the word stream --------------------------------------------------------------------------
 // std::generate_canonical<double, 53>(mt19937) (random.tcc:3348-3380): two words, sum = w0 + w1 * 2^32 rounded once, / 2^64
@@ -452,33 +525,56 @@ __global__ void __launch_bounds__(256) mt_polar_kernel(const PolarArgs a) {
     }
     __syncthreads();
     if (!a.out) return;
-    unsigned long long g0 = s_excl;
-    for (int v = 0; v < wv; ++v) g0 += wsum[v];
-    if (g0 >= a.need) return;
+    const unsigned long long excl = s_excl;
+    if (excl >= a.need) return;
+    // frame and position of the workgroup's first item, by ONE 64-bit division; the items of a workgroup are at most 2048 further on,
+    // so theirs follow with 32-bit arithmetic
+    unsigned long long f0 = 0;
+    uint32_t i0 = 0, c0 = 0;
+    const uint32_t pf = (uint32_t)a.per_frame;
+    if (pf) {
+        f0 = excl / pf;
+        i0 = (uint32_t)(excl - f0 * pf);
+        if (a.tx) c0 = (uint32_t)(((unsigned long long)a.first_frame + f0) % (unsigned long long)a.ncw);
+    }
+    uint32_t r0 = 0;   // items of the workgroup in front of this lane's
+    for (int v = 0; v < wv; ++v) r0 += wsum[v];
+    const double inv_s2_den = a.sigma * a.sigma;
 #pragma unroll
     for (int sub = 0; sub < kPolarSub; ++sub) {
         const bool ok = (bal[sub] >> lane) & 1ull;
-        const unsigned long long g = g0 + (unsigned long long)__popcll(bal[sub] & ((1ull << lane) - 1ull));
-        g0 += (unsigned long long)__popcll(bal[sub]);
+        const uint32_t r = r0 + (uint32_t)__popcll(bal[sub] & ((1ull << lane) - 1ull));
+        r0 += (uint32_t)__popcll(bal[sub]);
+        const unsigned long long g = excl + r;
         if (!ok || g >= a.need) continue;
         long long f = 0;
-        int i = 0;
-        if (a.per_frame) {   // a shard only evaluates the samples of its own frames
-            f = (long long)(g / (unsigned long long)a.per_frame);
-            i = (int)(g - (unsigned long long)f * (unsigned long long)a.per_frame);
+        uint32_t i = 0, df = 0;
+        if (pf) {   // a shard only evaluates the samples of its own frames
+            const uint32_t t = i0 + r;
+            df = t / pf;
+            i = t - df * pf;
+            f = (long long)(f0 + df);
             if (f < a.row_lo || f >= a.row_hi) continue;
         }
         const double r2 = r2s[sub];
-        const double mult = sqrt(-2.0 * ldpc_spec::log_glibc(r2) / r2);   // random.tcc:1827
+        // random.tcc:1827  mult = sqrt(-2 log(r2) / r2).  0 < r2 <= 1 and r2 >= 2^-106, 0 <= -2 log(r2) < 150: far from every case the
+        // scaling / fix-up instructions of the compiler's division exist for, so the shorter sequence returns the same bits
+        // (ldpc_spec::div_ranged; a numerator of -0.0, r2 == 1, ends as +0.0 here and there once `ret * 1.0 + 0.0` has been applied)
+        const double mult = sqrt(ldpc_spec::div_ranged(-2.0 * ldpc_spec::log_glibc(r2), r2));
         double ret = ys[sub] * mult;                                         // :1830
         ret = ret * 1.0 + 0.0;                                               // :1833 stddev 1, mean 0
-        if (!a.per_frame) {
+        if (!pf) {
             a.out[g] = ret;
         } else {
-            const double c = a.tx ? (double)a.tx[(size_t)((a.first_frame + f) % a.ncw) * a.ntx + i] : 0.0;
-            const double v = -2.0 * (a.sigma * ret + 2.0 * c - 1.0) / (a.sigma * a.sigma);   // bp_simulation.cpp:603 / :610
-            const int o = a.scatter ? a.scatter[i] : i;                                      // :684
-            a.out[(f - a.row_lo) * (long long)a.per_frame + o] = o >= a.punct_start ? a.punct_val : v;   // :697-710
+            double c = 0.0;
+            if (a.tx) {
+                uint32_t cw = c0 + df;
+                cw = cw >= (uint32_t)a.ncw ? cw % (uint32_t)a.ncw : cw;
+                c = (double)a.tx[(size_t)cw * a.ntx + i];
+            }
+            const double v = -2.0 * (a.sigma * ret + 2.0 * c - 1.0) / inv_s2_den;   // bp_simulation.cpp:603 / :610
+            const int o = a.scatter ? a.scatter[i] : (int)i;                       // :684
+            a.out[(f - a.row_lo) * (long long)pf + o] = o >= a.punct_start ? a.punct_val : v;   // :697-710
         }
     }
 }

@@ -14,7 +14,8 @@ int mt_prepare(ldpc_hip_ctx *c) {
     HIP_TRY(hipMalloc(&m.d_end_t, sizeof(long long) * 2));
     HIP_TRY(hipMalloc(&m.d_counters, sizeof(unsigned long long) * 2));
     HIP_TRY(hipMalloc(&m.d_ticket, sizeof(unsigned) * 2));
-    HIP_TRY(hipMalloc(&m.d_bits, sizeof(uint32_t) * J.bits.size()));
+    HIP_TRY(hipMalloc(&m.d_bits, sizeof(uint32_t) * (J.bits.size() + ldpc_mt::kBitsPad)));
+    HIP_TRY(hipMemset(m.d_bits, 0, sizeof(uint32_t) * (J.bits.size() + ldpc_mt::kBitsPad)));
     HIP_TRY(hipMemcpy(m.d_bits, J.bits.data(), sizeof(uint32_t) * J.bits.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_mt::mt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(sizeof(uint32_t) * ldpc_mt::kSeqWords)));
@@ -141,7 +142,7 @@ int mt_generate(ldpc_hip_ctx *c, const MtWindow &w, hipStream_t st) {
             if (pl >= (size_t)kLevels) return fail(LDPC_HIP_EUNSUPPORTED, "exact-replay window starts beyond 2^%d words", kLog2Stride + kLevels);
             HIP_TRY(hipMemsetAsync(t1, 0, sizeof(uint32_t) * MTN, st));
             JumpArgs ja{m.d_states, m.d_bits + pl * kMaxBits, J.nbits[pl], 8, (int)(t0 - m.d_states) / MTN, (int)(t1 - m.d_states) / MTN};
-            hipLaunchKernelGGL(mt_jump_kernel, dim3(8), dim3(640), sizeof(uint32_t) * kSeqWords, st, ja);
+            hipLaunchKernelGGL(mt_jump_kernel, dim3(8), dim3(kJumpThreads), sizeof(uint32_t) * kSeqWords, st, ja);
             uint32_t *t = t0; t0 = t1; t1 = t;
         }
         HIP_TRY(hipMemcpyAsync(m.d_states, t0, sizeof(uint32_t) * MTN, hipMemcpyDeviceToDevice, st));
@@ -152,10 +153,10 @@ int mt_generate(ldpc_hip_ctx *c, const MtWindow &w, hipStream_t st) {
         const int parts = cnt >= 256 ? 1 : cnt >= 128 ? 2 : cnt >= 64 ? 4 : 8;   // few jumps: spread each over several CUs
         const size_t pl = pl0 + (size_t)level;   // the polynomial of 2^(ls + level) words
         JumpArgs ja{m.d_states, m.d_bits + pl * kMaxBits, J.nbits[pl], parts, 0, (int)have};
-        hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(cnt * parts)), dim3(640), sizeof(uint32_t) * kSeqWords, st, ja);
+        hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(cnt * parts)), dim3(kJumpThreads), sizeof(uint32_t) * kSeqWords, st, ja);
     }
     GenArgs ga{m.d_states, m.d_xraw, (int)w.S, w.first, w.ls, w.gen_words};
-    hipLaunchKernelGGL(mt_generate_kernel, dim3((unsigned)((w.S + 3) / 4)), dim3(256), 0, st, ga);
+    hipLaunchKernelGGL(mt_generate_kernel, dim3((unsigned)w.S), dim3(kGenThreads), 0, st, ga);
     HIP_TRY(hipGetLastError());
     return 0;
 }
