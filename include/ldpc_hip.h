@@ -174,8 +174,8 @@ int ldpc_hip_qam_demod_dev(int Q, double T, double sigma, const double *d_x, lon
 int ldpc_hip_encode_host(int rh, int nh, int M, const int16_t *hd, const uint8_t *info_bits, uint8_t *codeword);
 
 /* The same encoder on the device (csrc/ldpc_encode.hpp): d_info_bits [B][(nh-rh)*M] bytes 0/1 -> d_codewords [B][nh*M] bytes, parity
- * first, identical to ldpc_hip_encode_host.  Base matrices with one dual-diagonal block (what upstream's search produces); matrices
- * made of several blocks (bp_simulation.cpp:142-191) are refused here and stay with the host encoder. */
+ * first, identical to ldpc_hip_encode_host -- also for base matrices whose parity part consists of several dual-diagonal blocks
+ * (bp_simulation.cpp:142-191: encoded from the last block to the first). */
 int ldpc_hip_encode_dev(ldpc_hip_ctx *ctx, const uint8_t *d_info_bits, long long B, uint8_t *d_codewords, void *stream);
 /* A table of ncw random codewords made on the device (information bits from Philox4x32-10 keyed by seed and codeword index, then the
  * device encoder) and installed like ldpc_hip_set_codewords: global frame f carries codeword f % ncw.  ncw == 0 returns to the all-zero

@@ -3,8 +3,8 @@
 // qc_encode (bp_simulation.cpp:22-117; host restatement: include/ldpc/encoder.h): partial syndromes of the information part per
 // block row, their sum over the block rows, then back-substitution along the double diagonal.  Every step is a XOR of rotated M-bit
 // slices, i.e. byte / bit work with one frame per workgroup: thread h owns position h of every block (the rotations go through
-// LDS), two barriers per frame.  Single-block base matrices (what upstream's search produces, files/*.jsonx); matrices made of
-// several bidiagonal blocks (bp_simulation.cpp:142-191) stay with the host encoder.
+// LDS), a few barriers per frame.  The parity part may consist of several bidiagonal / unidiagonal blocks (bp_simulation.cpp:142-191):
+// they are encoded from the last to the first, each against the information part and the parity of the blocks behind it.
 //   random_info_kernel      information bits from Philox4x32-10 keyed by (seed, codeword index, word)
 //   qc_encode_kernel        information bits -> codewords (bytes 0/1, parity first)
 //   cw_channel_order_kernel codewords -> transmit order through the direct interleaver map, zero padded to whole symbols (:570,:575)
@@ -40,14 +40,21 @@ __global__ void __launch_bounds__(256) random_info_kernel(const RandomInfoArgs a
     }
 }
 
+constexpr int kEncMaxBlocks = 16;
+
 struct EncodeArgs {
     const uint8_t *info;   // [B][(c - b) * M]
     uint8_t *cw;           // [B][c * M]
     long long B;
     const int *hd;         // [b][c] shifts, negative = empty
     int b, c, M;
-    int single;            // bp_simulation.cpp:33 "is_single_diagonal"
-    int p;                 // :36-39 first row with a positive shift in the special parity column b - 1
+    // bp_simulation.cpp:142-191: the parity part may consist of several bidiagonal / unidiagonal blocks (:143-156); block q spans block
+    // rows (and parity block columns) [off[q], hi[q]) and is encoded against everything to its right -- the information part and the
+    // parity of the blocks after it -- so the blocks run from the last to the first (:167-185).  One block is the usual case.
+    int nblk;
+    int off[kEncMaxBlocks], hi[kEncMaxBlocks];
+    int single[kEncMaxBlocks];   // :33 "is_single_diagonal" of the block
+    int p[kEncMaxBlocks];        // :36-39 first row of the block with a positive shift in its special parity column hi - 1
 };
 
 __global__ void __launch_bounds__(256) qc_encode_kernel(const EncodeArgs a) {
@@ -58,46 +65,49 @@ __global__ void __launch_bounds__(256) qc_encode_kernel(const EncodeArgs a) {
     for (long long fr = blockIdx.x; fr < a.B; fr += gridDim.x) {
         for (int i = tid; i < n; i += T) cword[i] = i < r ? (uint8_t)0 : (uint8_t)(a.info[fr * (n - r) + (i - r)] & 1);
         __syncthreads();
-        for (int idx = tid; idx < r; idx += T) {                       // :49-62 partial syndromes of the information part
-            const int i = idx / M, h = idx - i * M;
-            uint8_t s = 0;
-            for (int j = b; j < c; ++j) {
-                const int sh = at(i, j);
-                if (sh >= 0) s ^= cword[j * M + (h + sh) % M];
+        for (int q = a.nblk - 1; q >= 0; --q) {
+            const int off = a.off[q], hi = a.hi[q], rb = hi - off;
+            for (int idx = tid; idx < rb * M; idx += T) {                  // :49-62 partial syndromes over everything right of the block
+                const int i = off + idx / M, h = idx % M;
+                uint8_t s = 0;
+                for (int j = hi; j < c; ++j) {
+                    const int sh = at(i, j);
+                    if (sh >= 0) s ^= cword[j * M + (h + sh) % M];
+                }
+                synd[idx] = s;
             }
-            synd[idx] = s;
-        }
-        __syncthreads();
-        for (int h = tid; h < M; h += T) {
-            uint8_t s = 0;
-            for (int i = 0; i < b; ++i) s ^= synd[i * M + h];
-            sum[h] = s;
-        }
-        __syncthreads();
-        if (a.single) {
-            for (int i = tid; i < r; i += T) cword[i] = synd[i];       // :64-68
-        } else {
-            const int sp = at(a.p, b - 1), s0 = at(0, b - 1);
-            for (int h = tid; h < M; h += T) {                          // :70-84 back-substitution along the double diagonal
-                const uint8_t xh = sum[(h + M - sp) % M];
-                cword[(b - 1) * M + h] = xh;
-                uint8_t v = synd[h];
-                if (s0 == 0) v ^= xh;
-                if (s0 > 0) v ^= sum[h];
-                cword[h] = v;
-                uint8_t prev = v;
-                for (int i = 1; i < b - 1; ++i) {
-                    const int idx = i * M + h;
-                    uint8_t w = synd[idx] ^ prev;
-                    const int si = at(i, b - 1);
-                    if (si == 0) w ^= xh;
-                    if (si > 0) w ^= sum[h];
-                    cword[idx] = w;
-                    prev = w;
+            __syncthreads();
+            for (int h = tid; h < M; h += T) {
+                uint8_t s = 0;
+                for (int i = 0; i < rb; ++i) s ^= synd[i * M + h];
+                sum[h] = s;
+            }
+            __syncthreads();
+            if (a.single[q]) {
+                for (int i = tid; i < rb * M; i += T) cword[off * M + i] = synd[i];   // :64-68
+            } else {
+                const int sp = at(off + a.p[q], hi - 1), s0 = at(off, hi - 1);
+                for (int h = tid; h < M; h += T) {                          // :70-84 back-substitution along the double diagonal
+                    const uint8_t xh = sum[(h + M - sp) % M];
+                    cword[(hi - 1) * M + h] = xh;
+                    uint8_t v = synd[h];
+                    if (s0 == 0) v ^= xh;
+                    if (s0 > 0) v ^= sum[h];
+                    cword[off * M + h] = v;
+                    uint8_t prev = v;
+                    for (int i = 1; i < rb - 1; ++i) {
+                        const int idx = i * M + h;
+                        uint8_t w = synd[idx] ^ prev;
+                        const int si = at(off + i, hi - 1);
+                        if (si == 0) w ^= xh;
+                        if (si > 0) w ^= sum[h];
+                        cword[off * M + idx] = w;
+                        prev = w;
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
         for (int i = tid; i < n; i += T) a.cw[fr * n + i] = cword[i];
         __syncthreads();
     }

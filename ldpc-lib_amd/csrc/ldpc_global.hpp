@@ -11,7 +11,8 @@
 //   sp_global_kernel   sum_prod_decod_qc_lm  decoders.cpp:1923-2185: the four phases of ldpc_sumprod.hpp, arrays in the workspace.
 //   ims_global_kernel  imin_sum_decod_qc_lm  decoders.cpp:5430-5690: min-sum on ints, saturation after every add of STATE1 (:5568).
 //   bp_global_kernel   bp_decod_qc_lm        decoders.cpp:1708-1920, with the frame chain of the resident kernel.
-//   asp_global_kernel  sum_prod_gf2_decod_qc_lm  decoders.cpp:2324-2581 (general branch).
+//   asp_global_kernel  sum_prod_gf2_decod_qc_lm  decoders.cpp:2324-2581 (the general branch, and the branch for codes whose block
+//                      columns all hold exactly two circulants, :2431-2480).
 //   tasp_global_kernel tdmp_sum_prod_gf2_decod_qc_lm  decoders.cpp:2584-2744 (decoder 7, the decoder of upstream's shipped scenarios):
 //                      per-edge lambda / rho / forward / backward products in the workspace instead of VGPRs, so row weight and
 //                      the number of circulants are unbounded (the resident tasp_body holds <= 144 edges in registers).
@@ -46,6 +47,7 @@ struct GlobArgs {
     uint32_t *synd_out;       // same layout: what this frame leaves behind, or null
     const int *frame_idx;     // [slots] frame decoded by each workgroup slot, or null = the slot index
     long long slots;          // workgroup slots of this launch (B, or the number of frames of a re-decode pass)
+    int asp_cw2;              // asp_global_kernel: every block column holds exactly two circulants -> upstream's own branch (decoders.cpp:2431-2480)
     const double *ims_coef;   // ims_global_kernel: [B] sqrt(N / sum y^2) per frame (ims_coef_kernel: the sum is sequential, its rounding is part of the result)
 };
 
@@ -496,8 +498,8 @@ __global__ void __launch_bounds__(kGlobThreads) ims_global_kernel(const GlobArgs
     }
 }
 
-// sum_prod_gf2_decod_qc_lm, decoders.cpp:2324-2581 (probability domain, flooding; general branch :2482-2556 -- codes whose block
-// columns ALL have weight 2 take upstream's other branch and are refused by the host like in the resident tier).
+// sum_prod_gf2_decod_qc_lm, decoders.cpp:2324-2581 (probability domain, flooding): the general branch :2482-2556 and -- GlobArgs::asp_cw2
+// -- the branch upstream takes for codes whose block columns ALL hold exactly two circulants (:2431-2480; only this tier runs it).
 // Workspace: state[e][n] per circulant and check (upstream's state[slot][row*m + n]) + two scratch arrays for map_bin's forward /
 // backward products; channel P(bit = 1) in aux, a-posteriori values in soft.
 __global__ void __launch_bounds__(kGlobThreads) asp_global_kernel(const GlobArgs g) {
@@ -557,6 +559,30 @@ __global__ void __launch_bounds__(kGlobThreads) asp_global_kernel(const GlobArgs
                 st(rw - 1) = (1 - sf(rw - 2)) / 2;
             }
             __syncthreads();
+            if (g.asp_cw2) {
+                // every block column has exactly two circulants: upstream's own branch (:2431-2480) -- the messages are formed from the
+                // channel value and the OTHER edge directly, and nothing is clamped
+                for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {
+                    const int k = v / M, t = v - k * M;
+                    const int q0 = a.col_start[k], q1 = q0 + 1;                     // hci[i][0] < hci[i][1]: rows ascending
+                    int n0 = t - (int)(a.col_edges[q0] & 0xffffu), n1 = t - (int)(a.col_edges[q1] & 0xffffu);
+                    if (n0 < 0) n0 += M;
+                    if (n1 < 0) n1 += M;
+                    const size_t z0 = (size_t)a.col_slot[q0] * M + n0, z1 = (size_t)a.col_slot[q1] * M + n1;
+                    const double d0 = ST[z0], d1 = ST[z1];                          // data0[k], data1[k] :2449-2450
+                    double p1 = p1ch[v];
+                    double q10 = p1, q11 = p1, p0 = 1.0 - p1, q00 = 1.0 - p1, q01 = 1.0 - p1;   // :2454-2459
+                    q10 = q10 * d1;                                                 // :2461-2466
+                    q00 = q00 * (1 - d1);
+                    q11 = q11 * d0;
+                    q01 = q01 * (1 - d0);
+                    p1 = q10 * d0;
+                    p0 = q00 * (1 - d0);
+                    w.soft[v] = p1 / (p0 + p1);                                     // :2469
+                    ST[z0] = q10 / (q10 + q00);                                     // :2471
+                    ST[z1] = q11 / (q11 + q01);                                     // :2472
+                }
+            } else
             for (int v = threadIdx.x; v < N; v += (int)blockDim.x) {                // symbol nodes + local data update :2482-2556
                 const int k = v / M, t = v - k * M;
                 double P1 = p1ch[v], P0 = 1 - p1ch[v];

@@ -164,6 +164,7 @@ struct ldpc_hip_ctx {
     double ims_thr = 1.4;  // MS_THR, MS_QBITS, MS_DBITS (decoders.h:46-48), see ldpc_hip_set_ims_params
     int ims_qbits = 6, ims_dbits = 8;
     // shape-unlimited tier (ldpc_global.hpp): message state in a workspace in global memory
+    bool asp_cw2 = false;    // ASP_DEC on a code whose block columns all hold two circulants: upstream's own branch, on this tier only
     bool global_tier = false;
     char *d_glob_ws = nullptr;
     size_t glob_stride = 0;
@@ -338,7 +339,7 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
         break;
     }
     case LDPC_HIP_ASP_DEC: {
-        p.required = true;  // code-specialised instances only; upstream's all-columns-of-weight-2 branch (decoders.cpp:2431-2480) is not built
+        p.required = true;  // code-specialised instances only; upstream's all-columns-of-weight-2 branch (decoders.cpp:2431-2480) runs on the shape-unlimited tier
         const size_t lds = sizeof(double) * (size_t)t.ne * M + (((size_t)N + 15) & ~(size_t)15) + 16;
         bool all_cw2 = true;
         for (int k = 0; k < t.nh; ++k) all_cw2 = all_cw2 && (t.col_start[k + 1] - t.col_start[k] == 2);
@@ -478,10 +479,12 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
     c->have_generic = have_generic;
     if (have_generic) c->generic_name = c->kernel_name;
 
-    bool all_cw2 = true;   // upstream's all-columns-of-weight-2 branch of decoder 2 (decoders.cpp:2431-2480) is not built
+    bool all_cw2 = true;   // decoder 2 has its own branch for codes whose block columns all hold two circulants (decoders.cpp:1027-1044,
+                           // :2431-2480): the shape-unlimited tier runs it (asp_global_kernel), the resident asp_body is the general branch
     for (int k = 0; k < nh; ++k) all_cw2 = all_cw2 && (t.col_start[k + 1] - t.col_start[k] == 2);
+    c->asp_cw2 = decoder_id == LDPC_HIP_ASP_DEC && all_cw2;
     const bool can_global = decoder_id == LDPC_HIP_BP_DEC || decoder_id == LDPC_HIP_MS_DEC || decoder_id == LDPC_HIP_LMS_DEC || decoder_id == LDPC_HIP_SP_DEC || decoder_id == LDPC_HIP_IMS_DEC ||
-                            (decoder_id == LDPC_HIP_TASP_DEC && t.min_rw >= 2) || (decoder_id == LDPC_HIP_ASP_DEC && t.min_rw >= 2 && !all_cw2);
+                            (decoder_id == LDPC_HIP_TASP_DEC && t.min_rw >= 2) || (decoder_id == LDPC_HIP_ASP_DEC && t.min_rw >= 2);
 
     // ---- code-specialised instance: ahead of time for the shipped example code, hiprtc for anything else
     const SpecPlan plan = plan_spec(decoder_id, t);
@@ -533,7 +536,7 @@ int ldpc_hip_open(int decoder_id, int rh, int nh, int M, const int16_t *hd, int 
         if (!have_generic)
             return fail(LDPC_HIP_EUNSUPPORTED, "decoder %d, code %dx%d lifting %d: not supported by the generic kernel (limits: %d block rows, "
                         "%d block columns, row weight %d, M <= 512, 160 KiB LDS), no code-specialised instance: %s; the shape-unlimited "
-                        "tier serves every built decoder; decoders 2 and 7 need row weights >= 2, decoder 2 a block column of weight != 2",
+                        "tier serves every built decoder; decoders 2 and 7 need row weights >= 2",
                         decoder_id, rh, nh, M, kRHM, kNHM, kRWM, why_not.c_str());
         if (plan.body && c->variant >= 2 && !c->jit_job)
             fprintf(stderr, "[ldpc_hip] code-specialised kernel unavailable (%s); using %s\n", why_not.c_str(), c->kernel_name.c_str());
@@ -650,7 +653,7 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
         ga.d.col_slot = c->d_col_slot; ga.d.edge_row = c->d_edge_row;
         ga.d.B = B; ga.d.rh = c->rh; ga.d.nh = c->nh; ga.d.M = c->M; ga.d.N = c->N; ga.d.F = 1; ga.d.maxiter = maxiter;
         ga.d.hard_words = c->hard_words; ga.d.alpha = alpha;
-        ga.ws = c->d_glob_ws; ga.ws_stride = c->glob_stride; ga.ne = c->ne;
+        ga.ws = c->d_glob_ws; ga.ws_stride = c->glob_stride; ga.ne = c->ne; ga.asp_cw2 = c->asp_cw2 ? 1 : 0;
         if (c->decoder_id == LDPC_HIP_IMS_DEC) {
             if (B > c->ims_coef_frames) {
                 if (c->d_ims_coef) (void)hipFree(c->d_ims_coef);
@@ -951,11 +954,15 @@ static int encoder_setup(ldpc_hip_ctx *c, ldpc::EncodeArgs &ea) {
     const int b = c->rh, cc = c->nh, M = c->M;
     const int *mx = c->hd_int.data();
     auto at = [&](int i, int j) { return mx[i * cc + j]; };
-    for (int i = 1; i + 1 < b; ++i) {   // block boundaries of bp_simulation.cpp:143-156: several blocks stay with the host encoder
+    std::vector<int> brk(1, 0);         // block boundaries of bp_simulation.cpp:143-156, as include/ldpc/encoder.h finds them
+    for (int i = 1; i + 1 < b; ++i) {
         const bool bi = at(i, i) >= 0 && at(i + 1, i) >= 0 && at(i, i - 1) < 0;
         const bool uni = i > 1 && at(i, i) >= 0 && at(i + 1, i) < 0 && at(i, i - 1) < 0 && at(i - 1, i - 1) >= 0 && at(i - 1, i - 2) >= 0;
-        if (bi || uni) return fail(LDPC_HIP_EUNSUPPORTED, "the device encoder takes base matrices with one dual-diagonal block; this one has several: encode on the host (ldpc_hip_encode_host) and use ldpc_hip_set_codewords");
+        if (bi || uni) brk.push_back(i);
     }
+    brk.push_back(b);
+    if ((int)brk.size() - 1 > ldpc::kEncMaxBlocks)
+        return fail(LDPC_HIP_EUNSUPPORTED, "the device encoder takes up to %d dual-diagonal blocks; this base matrix has %d", ldpc::kEncMaxBlocks, (int)brk.size() - 1);
     if (cc <= b) return fail(LDPC_HIP_EUNSUPPORTED, "no information part to encode");
     const size_t lds = (size_t)c->N + (size_t)c->R + (size_t)M;
     if (lds > 150 * 1024) return fail(LDPC_HIP_EUNSUPPORTED, "code length %d is beyond the device encoder's LDS image", c->N);
@@ -965,10 +972,15 @@ static int encoder_setup(ldpc_hip_ctx *c, ldpc::EncodeArgs &ea) {
     const int rc = ldpc::encode(mx, b, cc, M, probe.data(), cw);
     if (rc != 0) return fail(LDPC_HIP_EUNSUPPORTED, "this base matrix is not encodable by the dual-diagonal encoder (code %d)", rc);
     ea.b = b; ea.c = cc; ea.M = M;
-    ea.single = b > 1 ? (at(1, 0) < 0) : 1;                                // bp_simulation.cpp:33
-    int p = 0;
-    while (p < b && at(p, b - 1) <= 0) ++p;                                 // :36-39
-    ea.p = p < b ? p : 0;
+    ea.nblk = (int)brk.size() - 1;
+    for (int q = 0; q < ea.nblk; ++q) {
+        const int off = brk[(size_t)q], hi = brk[(size_t)q + 1], rb = hi - off;
+        ea.off[q] = off; ea.hi[q] = hi;
+        ea.single[q] = rb > 1 ? (at(off + 1, off) < 0) : 1;               // bp_simulation.cpp:33 on the block's own sub-matrix
+        int p = 0;
+        while (p < rb && at(off + p, hi - 1) <= 0) ++p;                     // :36-39
+        ea.p[q] = p < rb ? p : 0;
+    }
     if (!c->d_hd_enc) {
         HIP_TRY(hipMalloc(&c->d_hd_enc, sizeof(int) * (size_t)b * cc));
         HIP_TRY(hipMemcpy(c->d_hd_enc, mx, sizeof(int) * (size_t)b * cc, hipMemcpyHostToDevice));

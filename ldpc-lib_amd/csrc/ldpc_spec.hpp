@@ -349,6 +349,25 @@ constexpr int kBpTabWords = 256 + 274;   // kExpTab + kLogData: bp_body keeps a 
 __device__ __forceinline__ double at_most(double x, double hi) { return fmin(x, hi); }
 __device__ __forceinline__ double at_least(double x, double lo) { return fmax(x, lo); }
 
+// Hard decisions of the variables [0, N) -> the frame's packed words, by T threads (whole waves): lane l of a wave looks at variable
+// 64 g + l, so that neighbouring lanes read neighbouring LDS words (conflict free), and a ballot makes two packed words at once.
+// (The loop this replaces gave word w to thread w and walked its 32 variables: every lane of a wave then read the same LDS bank,
+// a 64-way conflict per read -- ~19 % of the LDS-active cycles of the layered M = 512 and the TDMP M = 126 kernels in round 2's
+// counters, for the same bits.)
+template <int N, int T, class Pred>
+__device__ __forceinline__ void pack_hard(u32 *dst, const int tid, Pred pred) {
+    constexpr int G = (N + 63) / 64, HW = (N + 31) / 32;
+    const int lane = tid & 63;
+    for (int g = tid >> 6; g < G; g += T / 64) {
+        const int v = 64 * g + lane;
+        const u64 m = __ballot(v < N && pred(v < N ? v : 0));
+        if (lane == 0) {
+            dst[2 * g] = (u32)m;
+            if (2 * g + 1 < HW) dst[2 * g + 1] = (u32)(m >> 32);
+        }
+    }
+}
+
 
 template <class C>
 __device__ __forceinline__ void ms_m64_body(const SpecArgs &a) {
@@ -622,14 +641,7 @@ __device__ __forceinline__ void ms_body(const SpecArgs &a) {
                 if (lane == 0) reinterpret_cast<u64 *>(a.hard + fr * HW)[k * W + wave] = b;
             });
         } else {
-            for (int w = threadIdx.x; w < HW; w += W * 64) {
-                u32 bits = 0;
-                for (int b = 0; b < 32; ++b) {
-                    const int v = 32 * w + b;
-                    if (v < N) bits |= (*reinterpret_cast<const u32 *>(ldsb + (size_t)v * 8 + 4) >> 31) << b;
-                }
-                a.hard[fr * HW + w] = bits;
-            }
+            pack_hard<N, W * 64>(a.hard + fr * HW, threadIdx.x, [&](int v) { return (*reinterpret_cast<const u32 *>(ldsb + (size_t)v * 8 + 4) >> 31) != 0; });
         }
     }
     if (a.soft_out && valid) {
@@ -922,14 +934,7 @@ __device__ __forceinline__ void ms_chunk_body(const SpecArgs &a) {
     if (lane == 0 && a.iters) a.iters[fr] = res;
     if (a.hard) {
         constexpr int HW = (N + 31) / 32;
-        for (int w = lane; w < HW; w += 64) {
-            u32 bits = 0;
-            for (int b = 0; b < 32; ++b) {
-                const int v = 32 * w + b;
-                if (v < N) bits |= (*reinterpret_cast<const u32 *>(ldsb + (size_t)v * 8 + 4) >> 31) << b;
-            }
-            a.hard[fr * HW + w] = bits;
-        }
+        pack_hard<N, 64>(a.hard + fr * HW, lane, [&](int v) { return (*reinterpret_cast<const u32 *>(ldsb + (size_t)v * 8 + 4) >> 31) != 0; });
     }
     if (a.soft_out) {
         static_for<0, CH>([&](auto Q) {
@@ -1068,14 +1073,7 @@ __device__ __forceinline__ void lms_body(const SpecArgs &a) {
             });
         } else {
             constexpr int HW = (N + 31) / 32;
-            for (int w = threadIdx.x; w < HW; w += W * 64) {
-                u32 bits = 0;
-                for (int b = 0; b < 32; ++b) {
-                    const int v = 32 * w + b;
-                    if (v < N) bits |= (*reinterpret_cast<const u32 *>(ldsb + (size_t)v * 8 + 4) >> 31) << b;
-                }
-                a.hard[fr * HW + w] = bits;
-            }
+            pack_hard<N, W * 64>(a.hard + fr * HW, threadIdx.x, [&](int v) { return (*reinterpret_cast<const u32 *>(ldsb + (size_t)v * 8 + 4) >> 31) != 0; });
         }
     }
     if (a.soft_out && valid) {
@@ -1399,11 +1397,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
 
     if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
     if (a.hard) {
-        for (int w = threadIdx.x; w < (N + 31) / 32; w += T) {
-            u32 bits = 0;
-            for (int b = 0; b < 32; ++b) if (32 * w + b < N) bits |= (u32)hb[32 * w + b] << b;
-            a.hard[fr * ((N + 31) / 32) + w] = bits;
-        }
+        pack_hard<N, T>(a.hard + fr * ((N + 31) / 32), threadIdx.x, [&](int v) { return hb[v] != 0; });
     }
     if (a.soft_out) {
         static_for<0, NH * CH>([&](auto U) {
@@ -1553,14 +1547,7 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
     if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
     if (a.hard) {
         constexpr int HW = (N + 31) / 32;
-        for (int w = threadIdx.x; w < HW; w += W * 64) {
-            u32 bits = 0;
-            for (int b = 0; b < 32; ++b) {
-                const int v = 32 * w + b;
-                if (v < N) bits |= (u32)(*reinterpret_cast<const double *>(ldsb + (size_t)v * 8) > 0.5) << b;
-            }
-            a.hard[fr * HW + w] = bits;
-        }
+        pack_hard<N, W * 64>(a.hard + fr * HW, threadIdx.x, [&](int v) { return *reinterpret_cast<const double *>(ldsb + (size_t)v * 8) > 0.5; });
     }
     if (a.soft_out && valid) {
         static_for<0, NH>([&](auto K) {
@@ -1705,11 +1692,7 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
 
     if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
     if (a.hard) {
-        for (int w = threadIdx.x; w < (N + 31) / 32; w += T) {
-            u32 bits = 0;
-            for (int b = 0; b < 32; ++b) if (32 * w + b < N) bits |= (u32)hb[32 * w + b] << b;
-            a.hard[fr * ((N + 31) / 32) + w] = bits;
-        }
+        pack_hard<N, T>(a.hard + fr * ((N + 31) / 32), threadIdx.x, [&](int v) { return hb[v] != 0; });
     }
     if (a.soft_out) {
         static_for<0, NH * CH>([&](auto U) {
@@ -1876,11 +1859,7 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
         });
     }
     if (a.hard) {
-        for (int w = threadIdx.x; w < (N + 31) / 32; w += T) {
-            u32 bits = 0;
-            for (int b = 0; b < 32; ++b) if (32 * w + b < N) bits |= (u32)hb[32 * w + b] << b;
-            a.hard[fr * ((N + 31) / 32) + w] = bits;
-        }
+        pack_hard<N, T>(a.hard + fr * ((N + 31) / 32), threadIdx.x, [&](int v) { return hb[v] != 0; });
     }
     if (a.soft_out) {
         static_for<0, NH * CH>([&](auto U) {
@@ -2146,13 +2125,17 @@ __device__ __forceinline__ void ims_body_t(const SpecArgs &a) {
     phase_fence();
     if (a.hard) {
         constexpr int HW = (N + 31) / 32;
-        for (int w = SMALL ? n : (int)threadIdx.x; w < HW; w += SMALL ? M : W * 64) {
-            u32 bits = 0;
-            for (int b = 0; b < 32; ++b) {
-                const int v = 32 * w + b;
-                if (v < N) bits |= ((u32)(int)*reinterpret_cast<const signed char *>(softb + (v / M) * 2 * M + v % M) >> 31) << b;
+        if constexpr (SMALL) {
+            for (int w = n; w < HW; w += M) {
+                u32 bits = 0;
+                for (int b = 0; b < 32; ++b) {
+                    const int v = 32 * w + b;
+                    if (v < N) bits |= ((u32)(int)*reinterpret_cast<const signed char *>(softb + (v / M) * 2 * M + v % M) >> 31) << b;
+                }
+                a.hard[fr * HW + w] = bits;
             }
-            a.hard[fr * HW + w] = bits;
+        } else {
+            pack_hard<N, W * 64>(a.hard + fr * HW, threadIdx.x, [&](int v) { return *reinterpret_cast<const signed char *>(softb + (v / M) * 2 * M + v % M) < 0; });
         }
     }
     if (a.soft_out && valid) {

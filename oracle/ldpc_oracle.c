@@ -492,8 +492,7 @@ int orc_sum_prod_gf2(orc_code *c, double *soft, double *decword, int maxsteps, i
     double a[64], P[64], SF[64], SB[64];
     int v, e, j, n, i, q, steps, synd, all2 = 1;
 
-    for (i = 0; i < nh; i++) if (c->col_start[i + 1] - c->col_start[i] != 2) all2 = 0;
-    if (all2) return -9999; /* :2431-2480 uses different arithmetic; not restated */
+    for (i = 0; i < nh; i++) if (c->col_start[i + 1] - c->col_start[i] != 2) all2 = 0; /* decod_init :1027-1044: asp_all_cw_2 */
 
     for (v = 0; v < N; v++) { /* :2351-2358 */
         double x = soft[v] * 0.5;
@@ -522,6 +521,31 @@ int orc_sum_prod_gf2(orc_code *c, double *soft, double *decword, int maxsteps, i
                 for (s = 0; s < rw; s++) st[(size_t)(e0 + s) * M + n] = a[s];
             }
         }
+        if (all2) { /* every block column has exactly two circulants: upstream's own branch :2431-2480, no clamping, messages formed
+                     * from the channel value and the OTHER edge directly (hci[i][0] < hci[i][1]: rows ascending) */
+            for (i = 0; i < nh; i++) {
+                const int ea = c->col_edge[c->col_start[i]], eb = c->col_edge[c->col_start[i] + 1];
+                for (n = 0; n < M; n++) {
+                    int na = n - c->e_shift[ea], nb = n - c->e_shift[eb];
+                    double p1, p0, q10, q11, q00, q01, d0, d1;
+                    if (na < 0) na += M;
+                    if (nb < 0) nb += M;
+                    d0 = st[(size_t)ea * M + na]; /* data0[k], :2449 */
+                    d1 = st[(size_t)eb * M + nb]; /* data1[k], :2450 */
+                    p1 = soft[i * M + n];
+                    q10 = p1; q11 = p1; p0 = 1.0 - p1; q00 = 1.0 - p1; q01 = 1.0 - p1; /* :2454-2459 */
+                    q10 = q10 * d1;        /* :2461-2466 */
+                    q00 = q00 * (1 - d1);
+                    q11 = q11 * d0;
+                    q01 = q01 * (1 - d0);
+                    p1 = q10 * d0;
+                    p0 = q00 * (1 - d0);
+                    so[i * M + n] = p1 / (p0 + p1);            /* :2469 */
+                    st[(size_t)ea * M + na] = q10 / (q10 + q00); /* :2471 */
+                    st[(size_t)eb * M + nb] = q11 / (q11 + q01); /* :2472 */
+                }
+            }
+        } else {
         for (i = 0; i < nh; i++) { /* symbol nodes, overall products :2488-2520 */
             for (n = 0; n < M; n++) {
                 double P1 = soft[i * M + n], P0 = 1 - soft[i * M + n];
@@ -547,6 +571,7 @@ int orc_sum_prod_gf2(orc_code *c, double *soft, double *decword, int maxsteps, i
                     st[(size_t)ee * M + nn] = orc_maxd(orc_mind(d, 1.0 - 0.000001), 0.000001); /* SP_DEC_MAX/MIN_VAL :96-97 */
                 }
             }
+        }
         }
         synd = orc_syndrome_thr(c, so, 0.5); /* :2566 */
         if (synd == 0) {

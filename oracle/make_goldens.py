@@ -50,6 +50,16 @@ SETS = [
                                                         # upstream's uncleared syndrome array makes those return 1, not 0 (Q8)
     ("bp_m128_1p7",    BP_DEC,  128, 1.7, 8,  30, 2),
 ]
+# sets on other protographs than the example code: (name, decoder, code factory, M, snr, frames, maxiter, soft_frames)
+def _cycle_code(M):
+    from ldpc_testlib import cycle_code
+    return cycle_code(np.random.RandomState(1), 4, 8, M)
+
+
+EXTRA_SETS = [
+    # every block column holds exactly two circulants: sum_prod_gf2_decod_qc_lm's own branch (asp_all_cw_2, decoders.cpp:1027-1044, :2431-2480)
+    ("asp_cw2_m64_2p0", ASP_DEC, _cycle_code, 64, 2.0, 24, 40, 4),
+]
 ONLY = set(sys.argv[1:])  # optional: regenerate just the named sets
 
 
@@ -67,6 +77,23 @@ def main():
             clean = awgn_llr(H, M, 15.0, 2, frames)   # no channel errors: codewords at the decoder input
             for f in (0, 2, 6, 9, 10):               # 2, 6, 9 follow failed frames; 0 and 10 do not
                 llr[f] = clean[f]
+        ref = Reference(dec, H, M)
+        dec0, it0, after0 = ref.decode(dec, llr, maxiter, 0)
+        dec1, it1, _ = ref.decode(dec, llr[:soft_frames], maxiter, 1)
+        assert np.array_equal(it0[:soft_frames], it1)
+        np.savez_compressed(
+            os.path.join(GOLDEN_DIR, name + ".npz"),
+            H=H.astype(np.int16), M=np.int32(M), dec_id=np.int32(dec), snr=np.float64(snr), maxiter=np.int32(maxiter),
+            llr=llr, iters=it0.astype(np.int32), hard=pack_bits(dec0), soft=dec1,
+        )
+        print(f"{name}: frames={frames} iters={it0.tolist()[:12]}... fail={(it0 < 0).sum()} errbits={int((dec0 != 0).sum())}")
+        ref.close()
+
+    for name, dec, factory, M, snr, frames, maxiter, soft_frames in EXTRA_SETS:
+        if ONLY and name not in ONLY:
+            continue
+        H = factory(M)
+        llr = awgn_llr(H, M, snr, 1, frames)
         ref = Reference(dec, H, M)
         dec0, it0, after0 = ref.decode(dec, llr, maxiter, 0)
         dec1, it1, _ = ref.decode(dec, llr[:soft_frames], maxiter, 1)

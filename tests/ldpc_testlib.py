@@ -306,3 +306,43 @@ def random_qc_code(rng, rh, nh, M, info_weight):
         while (H[j, rh:] >= 0).sum() < 2:
             H[j, rh + rng.randint(0, nh - rh)] = rng.randint(0, M)
     return H
+
+
+def cycle_code(rng, rh, nh, M):
+    """A protograph in which EVERY block column has exactly two circulants (and every block row at least two): the shape upstream's
+    sum_prod_gf2_decod_qc_lm decodes in its own branch (asp_all_cw_2, decoders.cpp:1027-1044, :2431-2480)."""
+    while True:
+        H = -np.ones((rh, nh), dtype=np.int16)
+        for k in range(nh):
+            for j in rng.choice(rh, size=2, replace=False):
+                H[j, k] = rng.randint(0, M)
+        if ((H >= 0).sum(axis=1) >= 2).all():
+            return H
+
+
+def multi_block_code(rng, M, blocks=(4, 4), ninfo=6):
+    """A base matrix whose parity part consists of several dual-diagonal blocks (bp_simulation.cpp:142-191 encodes them from the last
+    to the first): block q has its own double diagonal and special column (shifts 0, s > 0, 0); earlier blocks' rows also touch the
+    parity columns of later blocks, which they treat like information columns."""
+    b = int(sum(blocks))
+    H = -np.ones((b, b + ninfo), dtype=np.int16)
+    off = 0
+    for rb in blocks:
+        hi = off + rb
+        for t in range(rb - 1):
+            H[off + t, off + t] = 0
+            H[off + t + 1, off + t] = 0
+        H[off, hi - 1] = 0
+        H[off + rb // 2, hi - 1] = 1 + rng.randint(0, max(M - 1, 1)) if M > 1 else 0
+        H[hi - 1, hi - 1] = 0
+        for _ in range(2):                       # rows of this block on parity columns of LATER blocks
+            if hi < b:
+                H[off + rng.randint(0, rb), rng.randint(hi, b)] = rng.randint(0, M)
+        off = hi
+    for k in range(b, b + ninfo):
+        for j in rng.choice(b, size=3, replace=False):
+            H[j, k] = rng.randint(0, M)
+    for j in range(b):
+        while (H[j, b:] >= 0).sum() < 1:
+            H[j, b + rng.randint(0, ninfo)] = rng.randint(0, M)
+    return H

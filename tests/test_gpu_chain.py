@@ -495,6 +495,28 @@ def test_device_encoder_equals_the_host_encoder(L, torch, M):
             assert not s.any()
 
 
+@pytest.mark.parametrize("M,blocks", [(64, (4, 4)), (7, (3, 5, 4)), (126, (5, 3)), (1, (4, 4, 4))])
+def test_device_encoder_on_several_dual_diagonal_blocks(L, torch, M, blocks):
+    """bp_simulation.cpp:142-191: a parity part made of several bidiagonal blocks is encoded from the last block to the first, each
+    against the information part and the parity of the blocks behind it.  Round 2's device encoder refused such matrices; now
+    ldpc_hip_encode_dev == ldpc_hip_encode_host on them, every word is a codeword, and a table of random codewords made on the
+    device decodes to itself."""
+    from ldpc_lib_amd.binding import encode
+    from ldpc_testlib import multi_block_code, syndrome_np
+    rng = np.random.RandomState(77 + M)
+    H = multi_block_code(rng, M, blocks)
+    b = sum(blocks)
+    info = rng.randint(0, 2, size=(29, (H.shape[1] - b) * M)).astype(np.uint8)
+    want = np.stack([encode(H, M, row) for row in info])
+    assert not syndrome_np(H, M, want).any()
+    with L.LdpcHip(MS_DEC, H, M) as dec:
+        got = dec.encode_dev(torch.from_numpy(info).cuda()).cpu().numpy()
+        assert np.array_equal(got, want)
+        dec.set_random_codewords(5, 40)
+        s = dec.simulate(12.0, 30, seed=3, first_frame=0, B=400)
+        assert s["frames"] == 400 and s["nde"] == 0
+
+
 def test_device_encoder_refuses_what_it_does_not_cover(L, torch):
     H = relift(load_base_matrix(), 64).copy()
     H[3, 2] = -1                      # breaks the double diagonal: not encodable at all

@@ -117,13 +117,7 @@ def test_shapes_beyond_the_resident_kernels_run_on_the_global_tier(L, torch, dec
 
 
 def test_what_the_global_tier_cannot_take_still_fails_loudly(L, torch):
-    """Decoder 2 on a code whose block columns all have weight 2 takes an upstream branch that is not built (decoders.cpp:2431-2480);
-    decoders 2 and 7 need two circulants per block row (map_bin reads past a one-element row upstream): error, no fallback."""
-    H = -np.ones((4, 8), dtype=np.int16)
-    for j in range(4):
-        H[j, j] = 0; H[(j + 1) % 4, j] = 1; H[j, 4 + j] = 2; H[(j + 2) % 4, 4 + j] = 3      # every column weight 2
-    with pytest.raises(L.LdpcHipError):
-        L.LdpcHip(ASP_DEC, H, 600)
+    """Decoders 2 and 7 need two circulants per block row (map_bin reads past a one-element row upstream): error, no fallback."""
     H1 = -np.ones((3, 6), dtype=np.int16)
     H1[0, 0] = 0; H1[1, 1] = 0; H1[2, 2] = 0; H1[1, 3] = 5; H1[2, 4] = 7; H1[1, 5] = 2; H1[2, 5] = 3  # block row 0 has a single circulant
     with pytest.raises(L.LdpcHipError):
@@ -132,7 +126,7 @@ def test_what_the_global_tier_cannot_take_still_fails_loudly(L, torch):
 
 @pytest.mark.parametrize("name", ["ms_m64_1p2", "ms_m126_1p7", "ms_m1_4p0", "ms_m512_1p6", "lms_m64_0p8", "lms_m512_1p0", "lms_m1_4p0",
                                   "tasp_m64_1p7", "tasp_m126_1p7", "tasp_m1_4p0", "sp_m64_1p2", "sp_m64_2p0", "sp_m1_4p0", "ims_m64_2p0",
-                                  "asp_m64_1p2", "asp_m128_1p7", "bp_m64_2p0", "bp_m128_1p7", "bp_m64_1p0_stale"])
+                                  "asp_m64_1p2", "asp_m128_1p7", "asp_cw2_m64_2p0", "bp_m64_2p0", "bp_m128_1p7", "bp_m64_1p0_stale"])
 def test_global_tier_on_the_compiled_references_vectors(L, torch, name, monkeypatch):
     """LDPC_HIP_FORCE_GLOBAL=1: the tier takes shapes the resident kernels normally serve, so it can be pinned by the golden
     vectors the compiled upstream code produced: hard bits, return values, soft values."""
@@ -177,8 +171,6 @@ def test_soak_slice_random_protographs_on_the_shape_unlimited_tier(L, torch, mon
         llr = np.concatenate([awgn_llr(H, M, s, 900 + case, frames // 2) for s in (2.0, 5.0)])
         llr[0, :3] = [0.0, -0.0, 40000.0]
         for dec_id in (MS_DEC, LMS_DEC, IMS_DEC, SP_DEC, TASP_DEC, ASP_DEC, BP_DEC):
-            if dec_id == ASP_DEC and ((H >= 0).sum(axis=0) == 2).all():
-                continue   # upstream's all-columns-of-weight-2 branch has its own test
             name, _ = _check(L, torch, dec_id, H, M, llr, 30, expect_kernel="global")
             done += 1
     assert done >= 42, done
@@ -238,3 +230,17 @@ def test_chain_changes_do_not_touch_the_shape_unlimited_tiers_workspace(L, torch
             assert np.array_equal(iters.cpu().numpy(), it_ref)
             assert np.array_equal(hard.cpu().numpy().view(np.uint32), pack_bits(d_ref))
             del junk
+
+
+@pytest.mark.parametrize("rh,nh,M,seed", [(4, 8, 64, 1), (3, 7, 33, 2), (6, 9, 126, 3), (5, 12, 1, 4), (7, 11, 300, 5)])
+def test_asp_on_codes_whose_columns_all_have_weight_two(L, torch, rh, nh, M, seed):
+    """sum_prod_gf2_decod_qc_lm's own branch for codes in which every block column holds exactly two circulants (asp_all_cw_2,
+    decoders.cpp:1027-1044, :2431-2480): round 2 refused them; the shape-unlimited tier now runs that branch -- hard bits, return
+    values and soft values equal the oracle's (which tests/test_oracle_vs_ref.py pins to the compiled reference on the same
+    shapes, and tests/golden/asp_cw2_m64_2p0.npz to its recorded output)."""
+    from ldpc_testlib import cycle_code
+    H = cycle_code(np.random.RandomState(seed), rh, nh, M)
+    llr = np.concatenate([awgn_llr(H, M, s, 300 + i, 12) for i, s in enumerate((0.0, 3.0, 6.0))])
+    llr[0, :5] = [0.0, -0.0, 25.0, -25.0, 1e-300]
+    name, it = _check(L, torch, ASP_DEC, H, M, llr, 25, expect_kernel="asp_global_kernel")
+    assert (it > 0).any()

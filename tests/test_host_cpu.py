@@ -435,6 +435,13 @@ def test_encoder_returns_the_unique_systematic_codeword():
         assert not syndrome_np(H, M, np.stack([ca, cb, cab])).any()
         assert np.array_equal(ca ^ cb, cab)
         assert not encode(H, M, np.zeros(K, dtype=np.uint8)).any()
+    from ldpc_testlib import multi_block_code
+    for M, blocks in ((64, (4, 4)), (7, (3, 5, 4)), (126, (5, 3))):      # several dual-diagonal blocks (bp_simulation.cpp:142-191)
+        Hb = multi_block_code(np.random.RandomState(77 + M), M, blocks)
+        K = (Hb.shape[1] - sum(blocks)) * M
+        a, b = rng.randint(0, 2, K).astype(np.uint8), rng.randint(0, 2, K).astype(np.uint8)
+        ca, cb, cab = encode(Hb, M, a), encode(Hb, M, b), encode(Hb, M, a ^ b)
+        assert np.array_equal(ca[sum(blocks) * M:], a) and not syndrome_np(Hb, M, np.stack([ca, cb, cab])).any() and np.array_equal(ca ^ cb, cab)
     bad = relift(load_base_matrix(), 8).copy()
     bad[:, 15] = -1                       # no special parity column any more
     bad[15, 15] = 0

@@ -55,3 +55,21 @@ def test_restatement_equals_compiled_reference_on_random_protographs(rh, nh, M, 
         d1, i1, a1 = Oracle(H, M).decode(dec_id, llr, 25, 0)
         d2, i2, a2 = Reference(dec_id, H, M).decode(dec_id, llr, 25, 0)
         assert np.array_equal(i1, i2) and np.array_equal(d1, d2, equal_nan=True) and np.array_equal(a1, a2, equal_nan=True), dec_id
+
+
+@pytest.mark.parametrize("rh,nh,M,seed", [(4, 8, 64, 1), (3, 7, 33, 2), (6, 9, 126, 3), (5, 12, 1, 4)])
+def test_asp_branch_for_codes_whose_columns_all_have_weight_two(rh, nh, M, seed):
+    """sum_prod_gf2_decod_qc_lm takes its own branch when every block column holds exactly two circulants (asp_all_cw_2,
+    decoders.cpp:1027-1044, :2431-2480: no clamping, messages formed from the channel value and the other edge directly): the
+    restatement against the compiled reference, hard decisions / return values / soft values / the clobbered input."""
+    from ldpc_testlib import cycle_code
+    H = cycle_code(np.random.RandomState(seed), rh, nh, M)
+    assert ((H >= 0).sum(axis=0) == 2).all()
+    llr = np.concatenate([awgn_llr(H, M, s, 300 + i, 12) for i, s in enumerate((0.0, 3.0, 6.0))])
+    llr[0, :5] = [0.0, -0.0, 25.0, -25.0, 1e-300]
+    for decision in (0, 1):
+        d1, i1, a1 = Oracle(H, M).decode(ASP_DEC, llr, 25, decision)
+        d2, i2, a2 = Reference(ASP_DEC, H, M).decode(ASP_DEC, llr, 25, decision)
+        assert np.array_equal(i1, i2), (i1, i2)
+        assert np.array_equal(d1, d2, equal_nan=True) and np.array_equal(a1, a2, equal_nan=True)
+    assert (i1 > 0).any()                              # the decoder does work (not only codewords at the input)
