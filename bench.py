@@ -30,8 +30,8 @@ roofline (per kernel, also for every entry of "configs"):
                            profiles/r02_fetch_calibration.txt, + WRITE_SIZE) and the physical HBM fraction they give.
   valu_issue / lds         the BINDING roofs: vector instructions issued per second against the full-rate issue peak
                            (one wave64 VALU instruction per 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz) and LDS-array busy cycles.
-PMC figures come from profiles/r02_pmc.json (tools/prof_pmc2.sh); they are used only when the kernel sources hash to the
-value recorded there, otherwise the fields are null.
+PMC figures come from the newest profiles/r*_pmc.json (tools/prof_pmc2.sh) measured on exactly these kernel sources (a hash of
+csrc/ is recorded with them); otherwise the fields are null.
 """
 import argparse
 import hashlib
@@ -155,7 +155,7 @@ def exact_replay_block(ldpc_lib_amd, H, device, torch, pmc=None):
 
 
 def sources_hash():
-    """Hash of the kernel sources: PMC figures in profiles/r02_pmc.json are only quoted for the code they were measured on."""
+    """Hash of the kernel sources: PMC figures in profiles/r*_pmc.json are only quoted for the code they were measured on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "ldpc-lib_amd", "csrc")
     for sub in ("", "aot"):
@@ -168,13 +168,22 @@ def sources_hash():
 
 
 def load_pmc():
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-    except Exception:
-        return {}, "profiles/r02_pmc.json missing"
-    if pj.get("sources_hash") != sources_hash():
-        return {}, f"profiles/r02_pmc.json was measured on sources {pj.get('sources_hash')}, this tree is {sources_hash()}"
-    return pj.get("kernels", {}), None
+    """the newest profiles/r*_pmc.json that was measured on exactly these kernel sources"""
+    import glob
+    h = sources_hash()
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True)
+    seen = []
+    for f in files:
+        try:
+            pj = json.load(open(f))
+        except Exception:
+            continue
+        if pj.get("sources_hash") == h:
+            kern = pj.get("kernels", {})
+            kern["_file"] = os.path.relpath(f, ROOT)
+            return kern, None
+        seen.append(f"{os.path.basename(f)} ({pj.get('sources_hash')})")
+    return {}, f"no profiles/r*_pmc.json was measured on these sources ({h}); have: {', '.join(seen) or 'none'}"
 
 
 def roofline_block(kernel_name, kernel_ms_avg, launches, sum_iters_per_launch, frames_per_launch, bytes_iter, pmc, pmc_why, pmc_key):
@@ -193,7 +202,7 @@ def roofline_block(kernel_name, kernel_ms_avg, launches, sum_iters_per_launch, f
         hbm = (2.0 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0
         wave_iters = p["wave_iterations"]
         r["traffic"] = hbm
-        r["traffic_source"] = "profiles/r02_pmc.json (rocprofv3 --pmc, one pass per counter group, same launch shape; FETCH_SIZE x2 per profiles/r02_fetch_calibration.txt)"
+        r["traffic_source"] = f"{pmc.get('_file')} (rocprofv3 --pmc, one pass per counter group, same launch shape; FETCH_SIZE x2 per profiles/r02_fetch_calibration.txt)"
         r["hbm_physical"] = {"GBps": hbm / kern_s / 1e9, "frac": hbm / kern_s / 1e9 / HBM_PEAK_GBS, "bytes_per_frame": hbm / frames_per_launch}
         r["valu_issue"] = {"valu_insts_per_launch": p["SQ_INSTS_VALU"], "valu_insts_per_wave_iter": p["SQ_INSTS_VALU"] / wave_iters,
                            "cycles_per_inst": kern_s * CLOCK_HZ * SIMDS / p["SQ_INSTS_VALU"],

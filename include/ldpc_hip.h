@@ -221,7 +221,7 @@ int ldpc_hip_simulate(ldpc_hip_ctx *ctx, double snr_db, int modulation_type, int
  * Values equal the host's bit for bit on a host whose libm log() is glibc >= 2.28's FMA variant (the contract of the decoders'
  * exp / log above).  ldpc::bp_simulation_t (include/ldpc/bp_simulation.h) and the drop-in bp_simulation symbol use them, so the
  * exact-replay harness is no longer bound by the host generator (~7e3 frames/s per core at N = 2048). */
-/* host only, no GPU: the state 2^log2_words words further on (18 <= log2_words <= 29), as the device computes it: GF(2)
+/* host only, no GPU: the state 2^log2_words words further on (18 <= log2_words <= 30), as the device computes it: GF(2)
  * polynomial jump x^(2^k) mod the generator's minimal polynomial.  state_out[1..623] are the generator's words; of state_out[0]
  * only bit 31 is state (the recurrence never reads the rest). */
 int ldpc_hip_mt_jump_host(const uint32_t state_in[624], int log2_words, uint32_t state_out[624]);

@@ -10,7 +10,7 @@
 //       [Haramoto, Matsumoto, Nishimura, Panneton, L'Ecuyer 2008].  With x^J = g_J mod phi every word of the sequence obeys
 //       x[t+J] = XOR over the set bits i of g_J of x[t+i] -- a GF(2) convolution over 19937 + 624 consecutive words
 //       (mt_jump_kernel: the words in LDS, up to 8 workgroups per jump, each taking a share of g_J's ~10^4 set coefficients).  The host computes phi (Berlekamp-Massey on an output bit
-//       sequence) and g_J for J = 2^18 .. 2^29 by repeated squaring once per process (~60 ms) and checks the first against a plain
+//       sequence) and g_J for J = 2^18 .. 2^30 by repeated squaring once per process (~60 ms) and checks the first against a plain
 //       2^18-step walk.  S stream states are reached in ceil(log2 S) doubling rounds; then one WAVEFRONT per stream runs the
 //       recurrence in place over its 624-word block in LDS, 192 words per step with every LDS address an immediate offset
 //       (mt_generate_kernel), writing the untempered words to HBM.
@@ -38,7 +38,7 @@ constexpr int MTN = 624;
 constexpr int kLog2Stride = 18;                       // shortest stream: 2^18 words (a round picks 2^18, 2^19 or 2^20 by its size)
 constexpr int kLog2StrideMax = 20;
 constexpr long long kStride = 1ll << kLog2Stride;
-constexpr int kLevels = 12;                           // jump polynomials for 2^18 .. 2^29 words
+constexpr int kLevels = 13;                           // jump polynomials for 2^18 .. 2^30 words
 constexpr int kMaxStreams = 1024;                     // streams per round
 constexpr int kDegree = 19937;
 constexpr int kMaxBits = 10752;                        // set coefficients per polynomial: 19937 / 2 +- a few hundred
@@ -309,6 +309,8 @@ __device__ __forceinline__ void mt_lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// (Measured: 0.99 ms per 2^27-sample round for round 2's one-wave-per-stream kernel, 0.69 ms for this one; skipping the LDS accesses
+// a whole wave does not need -- the zero reads, the operands of word 623 -- behind wave-uniform branches made it slower, 0.78 ms.)
 // one block: x (old, LDS) -> nx (new, LDS) and out (HBM); xr = the thread's own words of the old block on entry, of the new on exit.
 // Everything address-like is a function of (thread, k) only, i.e. invariant over the block loop; no branch depends on data.
 template <int T>

@@ -46,7 +46,11 @@ struct MtWindow {
 inline int mt_log2_stride(long long words) {
     // stream length by the size of the job: the generate kernel is bound by the latency of one wave walking its stream, the jumps
     // by their number -- short streams for small rounds, 2^20 words for the 65536-frame batches
-    return words <= (1ll << 26) ? 18 : words <= (1ll << 28) ? 19 : ldpc_mt::kLog2StrideMax;
+    // 2^21-word streams halve the jumps of the largest rounds (0.90 -> 0.55 ms per 2^27 samples) but the word kernel then has too few
+    // workgroups to cover its barrier latency (0.69 -> 1.16 ms): 2^20 stays the longest (LDPC_HIP_MT_LOG2_STRIDE: experiments)
+    static const int cap = getenv("LDPC_HIP_MT_LOG2_STRIDE") ? atoi(getenv("LDPC_HIP_MT_LOG2_STRIDE")) : 20;
+    const int ls = words <= (1ll << 26) ? 18 : words <= (1ll << 28) ? 19 : words <= (1ll << 29) ? 20 : 21;
+    return ls < cap ? ls : (cap < 18 ? 18 : cap);
 }
 
 MtPlan mt_plan(long long pos, unsigned long long need) {

@@ -495,7 +495,7 @@ def test_device_encoder_equals_the_host_encoder(L, torch, M):
             assert not s.any()
 
 
-@pytest.mark.parametrize("M,blocks", [(64, (4, 4)), (7, (3, 5, 4)), (126, (5, 3)), (1, (4, 4, 4))])
+@pytest.mark.parametrize("M,blocks", [(64, (4, 4)), (7, (3, 5, 4)), (126, (5, 3)), (2, (4, 4, 4))])
 def test_device_encoder_on_several_dual_diagonal_blocks(L, torch, M, blocks):
     """bp_simulation.cpp:142-191: a parity part made of several bidiagonal blocks is encoded from the last block to the first, each
     against the information part and the parity of the blocks behind it.  Round 2's device encoder refused such matrices; now

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/pmc2/<config>/<group>/**/counter_collection.csv -> gpurun_out/r02_pmc.json (per config: counters per dispatch of the
+"""gpurun_out/pmc2/<config>/<group>/**/counter_collection.csv -> gpurun_out/<ROUND_TAG>_pmc.json (per config: counters per dispatch of the
 decode kernel, averaged over its dispatches, + launch shape) keyed by the hash of the kernel sources they were measured on."""
 import collections
 import csv
@@ -58,7 +58,7 @@ if acc:
     d["per_kernel"] = {k: {c: v / rounds for c, v in cs.items()} for k, cs in per_kernel.items()}
     out["kernels"]["exact_replay_generator"] = d
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r02_pmc.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", os.environ.get("ROUND_TAG", "r03") + "_pmc.json"), "w"), indent=1)
 for k, d in out["kernels"].items():
     if k == "exact_replay_generator":
         print(k, "HBM bytes/sample %.1f" % ((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024 / d["samples"]), "VALU insts/sample %.1f" % (d.get("SQ_INSTS_VALU", 0) * 64 / d["samples"]))

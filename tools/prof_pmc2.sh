@@ -1,9 +1,9 @@
 #!/bin/bash
 # PMC passes for every bench configuration (one rocprofv3 run per counter group, --pmc only, never combined with tracing),
-# output under gpurun_out/pmc2/<config>/<group>/, then tools/pmc_collect.py -> gpurun_out/r02_pmc.json (copy to profiles/).
+# output under gpurun_out/pmc2/<config>/<group>/, then tools/pmc_collect.py -> gpurun_out/$ROUND_TAG_pmc.json (copy to profiles/).
 # usage: prof_pmc2.sh [config keys...]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-KEYS=${@:-cfg2_min_sum cfg3_sum_product cfg4_layered_m512 cfg5_qam16_min_sum f1_integer_min_sum f2_tasp_m126 exact_replay_generator}
+KEYS=${@:-cfg2_min_sum cfg3_sum_product cfg4_layered_m512 cfg5_qam16_min_sum f1_integer_min_sum f2_tasp_m126 f2_bp_m64 f2_asp_m64 exact_replay_generator}
 run() { # key group counters...
   local key=$1 name=$2; shift 2
   timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc2/$key/$name -- python3 tools/pmc_workload.py $key > gpurun_out/pmc2/${key}_$name.log 2>&1 || { echo "pass $key/$name failed"; tail -5 gpurun_out/pmc2/${key}_$name.log; return 1; }
