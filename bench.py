@@ -73,7 +73,7 @@ def algorithmic_bytes_per_iter(formula, E, R, N):
 EXTRA_CONFIGS = [
     dict(key="cfg3_sum_product", dec=DEC_SP, M=64, frames=16384, maxiter=50, oper_snr=2.0, modulation=0, formula="sp",
          what="(2048,1024) sum-product 50 it (BASELINE configs[2])"),
-    dict(key="cfg4_layered_m512", dec=DEC_LMS, M=512, frames=4096, maxiter=50, oper_snr=1.6, modulation=0, formula="lms",
+    dict(key="cfg4_layered_m512", dec=DEC_LMS, M=512, frames=16384, maxiter=50, oper_snr=1.6, modulation=0, formula="lms",
          what="(16384,8192) layered min-sum 50 it, one GPU's shard (BASELINE configs[3])"),
     dict(key="cfg5_qam16_min_sum", dec=DEC_MS, M=64, frames=65536, maxiter=50, oper_snr=5.0, modulation=2, formula="ms",
          what="(2048,1024) min-sum 50 it behind the 16-QAM mapper / soft demapper (BASELINE configs[4])"),

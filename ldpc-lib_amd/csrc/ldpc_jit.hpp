@@ -131,7 +131,9 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
     };
     auto publish = [&](const Kernel &k) -> const Kernel * {
         std::lock_guard<std::mutex> lk(mu);
-        return &cache.emplace(key, k).first->second;   // a concurrent compile of the same instance: the first one stays
+        auto ins = cache.emplace(key, k);   // a concurrent compile of the same instance: the first one stays ...
+        if (!ins.second && k.mod && k.mod != ins.first->second.mod) (void)hipModuleUnload(k.mod);   // ... and the loser's module is released
+        return &ins.first->second;
     };
     if (const Kernel *k = lookup()) return k;
 
@@ -161,6 +163,13 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
         unsigned long long h = 1469598103934665603ull;   // FNV-1a 64
         auto mix = [&](const std::string &t) { for (unsigned char ch : t) { h ^= ch; h *= 1099511628211ull; } };
         mix(src); mix(hdr); mix("gfx950 -O3 -ffp-contract=off");
+        // ... and on who compiled it for what: the runtime / compiler version and the device's own architecture string, so that an
+        // upgrade of ROCm (or another GPU in the box) never picks up an object made by an older compiler
+        int rt_version = 0;
+        (void)hipRuntimeGetVersion(&rt_version);
+        mix("rt" + std::to_string(rt_version));
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) mix(prop.gcnArchName);
         char name[64];
         snprintf(name, sizeof name, "/ldpc_spec_%016llx.hsaco", h);
         cache_file = std::string(dir) + name;
@@ -205,7 +214,8 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
         return nullptr;
     }
     if (!cache_file.empty()) {   // best effort, atomically: a concurrent process either sees the whole file or none
-        const std::string tmp = cache_file + ".tmp" + std::to_string((long long)getpid());
+        static std::atomic<unsigned> tmp_serial{0};   // the foreground open and the background worker may write the same key at once
+        const std::string tmp = cache_file + ".tmp" + std::to_string((long long)getpid()) + "." + std::to_string(tmp_serial.fetch_add(1));
         std::ofstream of(tmp, std::ios::binary);
         if (of && of.write(bin.data(), (std::streamsize)bin.size()) && (of.close(), true)) {
             if (rename(tmp.c_str(), cache_file.c_str()) != 0) (void)remove(tmp.c_str());
