@@ -227,7 +227,9 @@ constexpr int kJumpThreads = 640;   // ten waves: thread t < 624 makes state wor
 // they therefore come through the VECTOR memory path (its own counter) from an address the compiler cannot see to be uniform, 64
 // at a time as sixteen 16-byte loads with progressive waits -- the table is padded, so reading ahead of a part's end is harmless.
 // Measured per 256 full jumps: 276 us with one s_load per eight exponents in front of every eight reads (round 2), 240 us this
-// way; 305 us with three words per thread and v_readlane broadcasts (four waves: too few to cover the LDS latency).
+// way; 305 us with three words per thread and v_readlane broadcasts (four waves); 220 us with 8-byte reads of word PAIRS (exponent
+// lists split by parity so that every pair is aligned; five waves) -- but 43 instead of 38 us for the small early rounds, no net
+// gain, not kept.  The LDS delivers ~45 bytes per clock and CU to this access pattern whatever the access width.
 __global__ void __launch_bounds__(kJumpThreads) mt_jump_kernel(const JumpArgs a) {
     extern __shared__ uint32_t mt_x[];   // kSeqWords
     const int tid = threadIdx.x;

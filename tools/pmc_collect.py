@@ -30,16 +30,15 @@ for key, c in cfgs.items():
             n[row["Counter_Name"]] += 1
     if not acc:
         continue
-    waves_per_frame = (c["M"] + 63) // 64 if c["dec"] not in (bench.DEC_SP,) else 8
-    if c["dec"] == bench.DEC_TASP:
-        waves_per_frame = (c["M"] + 63) // 64
+    waves_per_frame = {bench.DEC_SP: 4, bench.DEC_BP: 8, bench.DEC_ASP: 8}.get(c["dec"], (c["M"] + 63) // 64)
     d = {k: acc[k] / n[k] for k in acc}
     d["kernel"] = kname
     d["frames"] = c["frames"]
     d["iterations"] = c["maxiter"]
     d["waves"] = d.get("SQ_WAVES")
-    # wave-iterations = waves of one dispatch x iterations each runs at the worst-case point
-    d["wave_iterations"] = (d.get("SQ_WAVES") or c["frames"] * waves_per_frame) * c["maxiter"]
+    # wave-iterations = (waves a frame occupies) x frames x iterations each runs at the worst-case point.  The flagship launches
+    # PERSISTENT waves that pull frames from a queue, so SQ_WAVES (2048) is not the number of frame-waves any more.
+    d["wave_iterations"] = max(d.get("SQ_WAVES") or 0, c["frames"] * waves_per_frame) * c["maxiter"]
     out["kernels"][key] = d
 # the exact-replay generator: all ldpc_mt:: kernels of one generation round of 2^27 samples, summed (two rounds were run)
 acc, n = collections.defaultdict(float), collections.Counter()
