@@ -136,7 +136,7 @@ def exact_replay_block(ldpc_lib_amd, H, device, torch, pmc=None):
         gen_s = time.perf_counter() - t1
         del buf
     words = 4.0 / (np.pi / 4.0)             # mt19937 words per accepted polar attempt
-    bytes_per_sample = 3 * 4.0 * words + 8  # words written once, read by the count and the emit pass; one fp64 sample out
+    bytes_per_sample = 2 * 4.0 * words + 8  # words written once and read once (the fused count / scan / emit pass); one fp64 sample out
     traffic = None
     p = (pmc or {}).get("exact_replay_generator")
     if p and p.get("samples") == n:

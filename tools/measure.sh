@@ -5,10 +5,12 @@ export ROUND_TAG=$TAG
 # the kernel sources), bench.py plain -> ${TAG}_bench.json, bench.py under rocprofv3 --kernel-trace --stats -> kernel stats CSV.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$TAG
+if [ -z "$SKIP_PMC" ]; then   # (the two halves fit one 20-minute gpurun call each: SKIP_PMC=1 runs the second half only)
 rm -rf gpurun_out/pmc2
 bash tools/prof_pmc2.sh > gpurun_out/$TAG/pmc2.log 2>&1 || { tail -20 gpurun_out/$TAG/pmc2.log; exit 1; }
 tail -7 gpurun_out/$TAG/pmc2.log
 cp gpurun_out/${TAG}_pmc.json profiles/${TAG}_pmc.json
+fi
 timeout -k 10 600 python bench.py > gpurun_out/$TAG/${TAG}_bench.json 2> gpurun_out/$TAG/${TAG}_bench.err || { tail -5 gpurun_out/$TAG/${TAG}_bench.err; exit 1; }
 python3 - <<'PY'
 import json, os
