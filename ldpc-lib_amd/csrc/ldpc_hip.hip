@@ -296,6 +296,8 @@ int set_lds_limit(const void *kernel, size_t bytes) {
 // Which code-specialised body serves this decoder / code shape, if any.  `required`: no generic kernel exists.
 struct SpecPlan { const char *body = nullptr; int threads = 0; size_t lds = 0; bool required = false; int frames_per_block = 1; };
 
+constexpr size_t kLdsBudget = 160 * 1024 - 64;   // the bodies' dynamic LDS image; the rest is the frame queue's ticket word
+
 SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
     SpecPlan p;
     const int M = t.M, N = t.nh * t.M, W = (M + 63) / 64;
@@ -310,12 +312,12 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
         else if (M > 64 && M <= 128 && !(getenv("LDPC_HIP_MS_CHUNK") && atoi(getenv("LDPC_HIP_MS_CHUNK")) == 0)) {
             p.body = "ms_chunk_body"; p.threads = 64; p.lds = sizeof(double) * (size_t)N;   // one wave, two 64-lane chunks, no barriers
         }
-        else if (M >= 33 && M <= 512 && soft_lds <= 160 * 1024) { p.body = "ms_body"; p.threads = 64 * W; p.lds = soft_lds; }
+        else if (M >= 33 && M <= 512 && soft_lds <= kLdsBudget) { p.body = "ms_body"; p.threads = 64 * W; p.lds = soft_lds; }
         break;
     case LDPC_HIP_LMS_DEC:
         if (M <= 32) {   // several frames per wavefront
             p.body = "lms_small_body"; p.threads = 64; p.frames_per_block = 64 / M; p.lds = sizeof(double) * (size_t)N * (size_t)(64 / M);
-        } else if (M >= 33 && M <= 512 && soft_lds <= 160 * 1024) { p.body = "lms_body"; p.threads = 64 * W; p.lds = soft_lds; }
+        } else if (M >= 33 && M <= 512 && soft_lds <= kLdsBudget) { p.body = "lms_body"; p.threads = 64 * W; p.lds = soft_lds; }
         break;
     case LDPC_HIP_IMS_DEC: {   // int8 messages: MS_DBITS <= 8 and ialpha <= 16, checked per launch (the generic kernel takes the rest)
         const size_t lds = (((size_t)2 * N + 15) & ~(size_t)15) + (size_t)t.rh * 2 * LDPC_IMS_MSG_COPIES * M * 4 + 16;
@@ -323,19 +325,19 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
             const size_t Fr = 64 / M;
             p.body = "ims_small_body"; p.threads = 64; p.frames_per_block = (int)Fr;
             p.lds = ((Fr * 2 * N + 15) & ~(size_t)15) + Fr * (size_t)t.rh * 2 * LDPC_IMS_MSG_COPIES * M * 4 + 16;
-        } else if (M >= 33 && M <= 512 && t.max_rw <= 8 && lds <= 160 * 1024) { p.body = "ims_body"; p.threads = 64 * W; p.lds = lds; }
+        } else if (M >= 33 && M <= 512 && t.max_rw <= 8 && lds <= kLdsBudget) { p.body = "ims_body"; p.threads = 64 * W; p.lds = lds; }
         break;
     }
     case LDPC_HIP_SP_DEC: {
         const size_t lds = ldpc::sp_lds_bytes(t.ne, M, t.rh * M, N);
-        if (M >= 33 && lds <= 160 * 1024) { p.body = "sp_body"; p.threads = 64 * ldpc_spec::kSpBodyWaves; p.lds = lds; }
+        if (M >= 33 && lds <= kLdsBudget) { p.body = "sp_body"; p.threads = 64 * ldpc_spec::kSpBodyWaves; p.lds = lds; }
         break;
     }
     case LDPC_HIP_BP_DEC: {
         p.required = true;  // code-specialised instances only
         const size_t lds = ((((sizeof(double) + 1) * ((size_t)t.ne * M + (size_t)t.rh * M) + (size_t)N) + 15) & ~(size_t)15) + 16;
         const size_t with_tables = lds + (size_t)ldpc_spec::kBpTabWords * 8;   // exp / log tables in LDS when they fit (bp_body: TAB_LDS)
-        if (lds <= 160 * 1024) { p.body = "bp_body"; p.threads = 512; p.lds = with_tables <= 160 * 1024 ? with_tables : lds; }
+        if (lds <= kLdsBudget) { p.body = "bp_body"; p.threads = 512; p.lds = with_tables <= kLdsBudget ? with_tables : lds; }
         break;
     }
     case LDPC_HIP_ASP_DEC: {
@@ -343,7 +345,7 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
         const size_t lds = sizeof(double) * (size_t)t.ne * M + (((size_t)N + 15) & ~(size_t)15) + 16;
         bool all_cw2 = true;
         for (int k = 0; k < t.nh; ++k) all_cw2 = all_cw2 && (t.col_start[k + 1] - t.col_start[k] == 2);
-        if (t.min_rw >= 2 && !all_cw2 && lds <= 160 * 1024) { p.body = "asp_body"; p.threads = 512; p.lds = lds; }
+        if (t.min_rw >= 2 && !all_cw2 && lds <= kLdsBudget) { p.body = "asp_body"; p.threads = 512; p.lds = lds; }
         break;
     }
     case LDPC_HIP_TASP_DEC:
@@ -708,16 +710,21 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
         }
         sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
         sa.nframes = B;
-        // the flagship (M = 64 flooding min-sum, one frame per wave): persistent waves that pull frames from a queue
+        // One frame per workgroup, min-sum / layered min-sum / TDMP bodies (the frame loop costs the integer, SP and ASP bodies spilled
+        // registers, BP has its frame chain, the small-lifting bodies several frames per workgroup): PERSISTENT workgroups, one per
+        // resident slot of the chip, that pull frames from a queue (SpecArgs::queue) -- frames converge after different numbers of
+        // iterations, and the next frame should start the moment a slot is free, without a workgroup launch in between
         static const bool persist_on = !(getenv("LDPC_HIP_PERSISTENT") && atoi(getenv("LDPC_HIP_PERSISTENT")) == 0);
-        const bool persistent = persist_on && c->decoder_id == LDPC_HIP_MS_DEC && c->M == 64 && c->spec_threads == 64 && c->spec_frames_per_block == 1;
+        const bool persistent = persist_on && c->spec_frames_per_block == 1 &&
+                                (c->decoder_id == LDPC_HIP_MS_DEC || c->decoder_id == LDPC_HIP_LMS_DEC || c->decoder_id == LDPC_HIP_TASP_DEC);
         if (persistent) {
             if (!c->d_queue) HIP_TRY(hipMalloc(&c->d_queue, 64));
-            if (c->persist_grid == 0 || c->persist_jit != (c->spec_aot == nullptr)) {   // resident waves: occupancy x CUs (8 x 256 on an MI355X)
+            if (c->persist_grid == 0 || c->persist_jit != (c->spec_aot == nullptr)) {   // resident workgroups: occupancy x CUs (8 x 256 for the flagship)
                 int per_cu = 0, cus = 0;
-                hipError_t e = c->spec_aot ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, c->spec_aot, 64, c->spec_lds)
-                                           : hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, c->spec_jit->fn, 64, c->spec_lds);
-                if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 8; }
+                if (c->spec_aot) { if (int rc = set_lds_limit(c->spec_aot, c->spec_lds)) return rc; }
+                hipError_t e = c->spec_aot ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, c->spec_aot, c->spec_threads, c->spec_lds)
+                                           : hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, c->spec_jit->fn, c->spec_threads, c->spec_lds);
+                if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
                 HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
                 c->persist_grid = per_cu * (cus > 0 ? cus : 256);
                 c->persist_jit = c->spec_aot == nullptr;

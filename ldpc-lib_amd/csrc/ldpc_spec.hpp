@@ -354,6 +354,26 @@ __device__ __forceinline__ double at_least(double x, double lo) { return fmax(x,
 // (The loop this replaces gave word w to thread w and walked its 32 variables: every lane of a wave then read the same LDS bank,
 // a 64-way conflict per read -- ~19 % of the LDS-active cycles of the layered M = 512 and the TDMP M = 126 kernels in round 2's
 // counters, for the same bits.)
+// Frames of a PERSISTENT launch (SpecArgs::queue, see there): the workgroup decodes frame `first`, then frames gridDim.x + ticket
+// until nframes is reached.  Between two frames every wave passes a barrier, so the next frame's set-up finds the LDS image free.
+// Without a queue: the one frame.  QUEUED = false (several frames per workgroup: the small-lifting bodies): the one frame, always.
+template <bool QUEUED, class F>
+__device__ __forceinline__ void for_each_frame(const SpecArgs &a, long long fr, F body) {
+    if constexpr (!QUEUED) {
+        body(fr);
+    } else {
+        __shared__ unsigned q_ticket;
+        while (fr < a.nframes) {
+            body(fr);
+            if (!a.queue) break;
+            __syncthreads();
+            if (threadIdx.x == 0) q_ticket = atomicAdd(a.queue, 1u);
+            __syncthreads();
+            fr = (long long)gridDim.x + (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)q_ticket);   // every wave ends at fr >= nframes
+        }
+    }
+}
+
 template <int N, int T, class Pred>
 __device__ __forceinline__ void pack_hard(u32 *dst, const int tid, Pred pred) {
     constexpr int G = (N + 63) / 64, HW = (N + 31) / 32;
@@ -528,7 +548,7 @@ __device__ __forceinline__ void ms_body(const SpecArgs &a) {
     const bool valid = (M % 64 == 0) || n < M;
     const u32 n8 = (u32)(valid ? n : 0) * 8u;
     const double alpha = a.alpha;
-    const long long fr = blockIdx.x;
+    for_each_frame<true>(a, (long long)blockIdx.x, [&](const long long fr) {
 
     auto rot = [&](u32 base, auto S) -> u32 {
         constexpr int c = decltype(S)::value;
@@ -650,6 +670,7 @@ __device__ __forceinline__ void ms_body(const SpecArgs &a) {
             a.soft_out[fr * N + k * M + n] = *reinterpret_cast<const double *>(ldsb + n8 + k * (8 * M));
         });
     }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -806,7 +827,7 @@ __device__ __forceinline__ void ms_chunk_body(const SpecArgs &a) {
     char *const ldsb = reinterpret_cast<char *>(lds);
     const int lane = threadIdx.x;
     const double alpha = a.alpha;
-    const long long fr = blockIdx.x;
+    for_each_frame<true>(a, (long long)blockIdx.x, [&](const long long fr) {
     bool ok[CH];
     u32 n8[CH];
     static_for<0, CH>([&](auto Q) {
@@ -947,6 +968,7 @@ __device__ __forceinline__ void ms_chunk_body(const SpecArgs &a) {
             }
         });
     }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -969,7 +991,7 @@ __device__ __forceinline__ void lms_body(const SpecArgs &a) {
     const int n = threadIdx.x;       // check row inside a circulant == variable index inside a block column
     const bool valid = (M % 64 == 0) || n < M;
     const u32 n8 = (u32)(valid ? n : 0) * 8u;
-    const long long fr = blockIdx.x;
+    for_each_frame<true>(a, (long long)blockIdx.x, [&](const long long fr) {
 
     // byte offset inside a block column of variable (n + shift) mod M
     auto rot = [&](u32 base, auto S) -> u32 {
@@ -1086,6 +1108,7 @@ __device__ __forceinline__ void lms_body(const SpecArgs &a) {
             a.soft_out[fr * N + k * M + n] = *reinterpret_cast<const double *>(ldsb + n8 + k * (8 * M));
         });
     }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1294,7 +1317,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // lanes beyond the lifting in the last 64-lane chunk of a circulant sit out
     auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
-    const long long fr = blockIdx.x;
+    for_each_frame<false>(a, (long long)blockIdx.x, [&](const long long fr) {   // (a frame loop costs this body spilled registers: one frame per launch slot)
 
     FrameVote fvote;
     fvote.init(flag);
@@ -1409,6 +1432,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
             if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) a.soft_out[fr * N + k * M + ch * 64 + lane] = sf[q];
         });
     }
+    });
 }
 
 // a / b for operands whose range is known: the instruction sequence the compiler emits for an fp64 division is
@@ -1461,7 +1485,7 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
     const int n = threadIdx.x;
     const bool valid = (M % 64 == 0) || n < M;
     const u32 n8 = (u32)(valid ? n : 0) * 8u;
-    const long long fr = blockIdx.x;
+    for_each_frame<true>(a, (long long)blockIdx.x, [&](const long long fr) {
 
     auto rot = [&](u32 base, auto S) -> u32 {
         constexpr int c = decltype(S)::value;
@@ -1559,6 +1583,7 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
             a.soft_out[fr * N + k * M + n] = *reinterpret_cast<const double *>(ldsb + n8 + k * (8 * M));
         });
     }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1588,7 +1613,7 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // lanes beyond the lifting in the last 64-lane chunk of a circulant sit out
     auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
-    const long long fr = blockIdx.x;
+    for_each_frame<false>(a, (long long)blockIdx.x, [&](const long long fr) {   // (a frame loop costs this body spilled registers: one frame per launch slot)
 
     FrameVote fvote;
     fvote.init(flag);
@@ -1704,6 +1729,7 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
             if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) a.soft_out[fr * N + k * M + ch * 64 + lane] = so[q];
         });
     }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1934,7 +1960,8 @@ __device__ __forceinline__ void ims_body_t(const SpecArgs &a) {
     int *const flag = reinterpret_cast<int *>(lds0 + kMsgBase + F * kMsgBytes);
     const int f = SMALL ? (int)threadIdx.x / M : 0;
     const int n = SMALL ? (int)threadIdx.x - f * M : (int)threadIdx.x;
-    const long long fr = SMALL ? (long long)blockIdx.x * F + f : (long long)blockIdx.x;
+    const long long fr0 = SMALL ? (long long)blockIdx.x * F + f : (long long)blockIdx.x;
+    for_each_frame<false>(a, fr0, [&](const long long fr) {   // (a frame loop costs this body nine more spilled registers)
     const bool valid = SMALL ? (f < F && fr < a.nframes) : ((M % 64 == 0) || n < M);
     const int nv = valid ? n : 0;
     const long long frv = valid ? fr : 0;
@@ -2148,6 +2175,7 @@ __device__ __forceinline__ void ims_body_t(const SpecArgs &a) {
             a.soft_out[fr * N + k * M + n] = (double)*reinterpret_cast<const signed char *>(softb + k * 2 * M + n);
         });
     }
+    });
 }
 
 template <class C> __device__ __forceinline__ void ims_body(const SpecArgs &a) { ims_body_t<C, false>(a); }
