@@ -710,13 +710,14 @@ int ldpc_hip_decode_dev(ldpc_hip_ctx *c, const double *d_llr, long long B, int m
         }
         sa.llr = d_llr; sa.hard = d_hard; sa.iters = d_iters; sa.soft_out = d_soft; sa.maxiter = maxiter; sa.alpha = alpha;
         sa.nframes = B;
-        // One frame per workgroup, min-sum / layered min-sum / TDMP bodies (the frame loop costs the integer, SP and ASP bodies spilled
-        // registers, BP has its frame chain, the small-lifting bodies several frames per workgroup): PERSISTENT workgroups, one per
+        // One frame per workgroup, min-sum and layered min-sum bodies (the frame loop costs the integer, SP and ASP bodies spilled
+        // registers and the TDMP body 7 % of its speed; BP has its frame chain, the small-lifting bodies several frames per
+        // workgroup): PERSISTENT workgroups, one per
         // resident slot of the chip, that pull frames from a queue (SpecArgs::queue) -- frames converge after different numbers of
         // iterations, and the next frame should start the moment a slot is free, without a workgroup launch in between
         static const bool persist_on = !(getenv("LDPC_HIP_PERSISTENT") && atoi(getenv("LDPC_HIP_PERSISTENT")) == 0);
         const bool persistent = persist_on && c->spec_frames_per_block == 1 &&
-                                (c->decoder_id == LDPC_HIP_MS_DEC || c->decoder_id == LDPC_HIP_LMS_DEC || c->decoder_id == LDPC_HIP_TASP_DEC);
+                                (c->decoder_id == LDPC_HIP_MS_DEC || c->decoder_id == LDPC_HIP_LMS_DEC);
         if (persistent) {
             if (!c->d_queue) HIP_TRY(hipMalloc(&c->d_queue, 64));
             if (c->persist_grid == 0 || c->persist_jit != (c->spec_aot == nullptr)) {   // resident workgroups: occupancy x CUs (8 x 256 for the flagship)

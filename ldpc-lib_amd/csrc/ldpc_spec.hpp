@@ -1317,7 +1317,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // lanes beyond the lifting in the last 64-lane chunk of a circulant sit out
     auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
-    for_each_frame<false>(a, (long long)blockIdx.x, [&](const long long fr) {   // (a frame loop costs this body spilled registers: one frame per launch slot)
+    const long long fr = blockIdx.x;
 
     FrameVote fvote;
     fvote.init(flag);
@@ -1432,7 +1432,6 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
             if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) a.soft_out[fr * N + k * M + ch * 64 + lane] = sf[q];
         });
     }
-    });
 }
 
 // a / b for operands whose range is known: the instruction sequence the compiler emits for an fp64 division is
@@ -1485,7 +1484,7 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
     const int n = threadIdx.x;
     const bool valid = (M % 64 == 0) || n < M;
     const u32 n8 = (u32)(valid ? n : 0) * 8u;
-    for_each_frame<true>(a, (long long)blockIdx.x, [&](const long long fr) {
+    const long long fr = blockIdx.x;
 
     auto rot = [&](u32 base, auto S) -> u32 {
         constexpr int c = decltype(S)::value;
@@ -1583,7 +1582,6 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
             a.soft_out[fr * N + k * M + n] = *reinterpret_cast<const double *>(ldsb + n8 + k * (8 * M));
         });
     }
-    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1613,7 +1611,7 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // lanes beyond the lifting in the last 64-lane chunk of a circulant sit out
     auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
-    for_each_frame<false>(a, (long long)blockIdx.x, [&](const long long fr) {   // (a frame loop costs this body spilled registers: one frame per launch slot)
+    const long long fr = blockIdx.x;
 
     FrameVote fvote;
     fvote.init(flag);
@@ -1729,7 +1727,6 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
             if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) a.soft_out[fr * N + k * M + ch * 64 + lane] = so[q];
         });
     }
-    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1960,8 +1957,7 @@ __device__ __forceinline__ void ims_body_t(const SpecArgs &a) {
     int *const flag = reinterpret_cast<int *>(lds0 + kMsgBase + F * kMsgBytes);
     const int f = SMALL ? (int)threadIdx.x / M : 0;
     const int n = SMALL ? (int)threadIdx.x - f * M : (int)threadIdx.x;
-    const long long fr0 = SMALL ? (long long)blockIdx.x * F + f : (long long)blockIdx.x;
-    for_each_frame<false>(a, fr0, [&](const long long fr) {   // (a frame loop costs this body nine more spilled registers)
+    const long long fr = SMALL ? (long long)blockIdx.x * F + f : (long long)blockIdx.x;
     const bool valid = SMALL ? (f < F && fr < a.nframes) : ((M % 64 == 0) || n < M);
     const int nv = valid ? n : 0;
     const long long frv = valid ? fr : 0;
@@ -2175,7 +2171,6 @@ __device__ __forceinline__ void ims_body_t(const SpecArgs &a) {
             a.soft_out[fr * N + k * M + n] = (double)*reinterpret_cast<const signed char *>(softb + k * 2 * M + n);
         });
     }
-    });
 }
 
 template <class C> __device__ __forceinline__ void ims_body(const SpecArgs &a) { ims_body_t<C, false>(a); }
