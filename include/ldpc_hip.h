@@ -252,6 +252,29 @@ int ldpc_hip_mt_frames(ldpc_hip_ctx *ctx, double snr_db, int modulation_type, in
 int ldpc_hip_mt_frames_slice(ldpc_hip_ctx *ctx, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha, long long B,
                              long long lo, long long hi, int32_t *frame_info, int32_t *iters);
 
+/* The same stream with ONE PROCESS PER GPU: every rank holds a context whose generator is in the same state, and the ranks share the
+ * generator's tape out among themselves exactly as ldpc_hip_mt_frames_multi does over the shards of one process -- the three small
+ * exchanges are the caller's (torch.distributed, MPI, ...).  One round covers the next `frames` frames (<= 65536), rank r decodes
+ * frames [frames*r/n, frames*(r+1)/n):
+ *   1. ldpc_hip_mt_shard_begin   makes the sub-streams around this rank's frames and counts the accepted polar-method attempts of
+ *                                its stretch -> own_count;                                  all-gather the n counts
+ *   2. ldpc_hip_mt_shard_emit    counts[n] in: emits this rank's decoder inputs; out: frames_done (whole frames the round completes, the
+ *                                same on every rank), found (this rank holds the state the round ends in -> state_next), covered (0: an
+ *                                item of this rank lay outside its window);               all-gather (found, covered); broadcast
+ *                                state_next from the lowest rank with found = 1
+ *   3. ldpc_hip_mt_shard_commit  installs that state and decodes this rank's frames below frames_done: frame_info / iters receive
+ *                                min(frames*(r+1)/n, frames_done) - frames*r/n records.
+ * If any rank reports covered = 0 or none reports found = 1 -- an estimate failed; probability ~1e-15 per round -- every rank calls
+ * ldpc_hip_mt_shard_abandon and runs the round with ldpc_hip_mt_frames_slice instead (the whole tape on every rank): nothing has
+ * been changed before commit.  (ldpc_lib_amd.bp_simulation(exact_seed=...) under torch.distributed does all of this.) */
+int ldpc_hip_mt_shard_begin(ldpc_hip_ctx *ctx, double snr_db, int modulation_type, int punctured_blocks, long long frames, int rank, int n,
+                            unsigned long long *own_count);
+int ldpc_hip_mt_shard_emit(ldpc_hip_ctx *ctx, const unsigned long long *counts, int *found, int *covered, uint32_t state_next[624],
+                           long long *frames_done);
+int ldpc_hip_mt_shard_commit(ldpc_hip_ctx *ctx, const uint32_t state[624], long long frames_done, int maxiter, double alpha,
+                             int32_t *frame_info, int32_t *iters);
+void ldpc_hip_mt_shard_abandon(ldpc_hip_ctx *ctx);
+
 /* ---- several GPUs of one node (bp_simulation's frame loop sharded; north_star: RCCL all-reduce for the counters only) ----
  * One shard = one context + one HIP stream + one host thread.  devices[i] is the HIP ordinal of shard i; ordinals may repeat
  * (logical shards on one GPU: results are identical, the counters are then summed on the host because RCCL does not accept one

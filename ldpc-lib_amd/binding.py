@@ -164,6 +164,11 @@ def load_library():
     lib.ldpc_hip_mt_set_frame_index_multi.argtypes = [vp, i64]
     lib.ldpc_hip_mt_advance_multi.argtypes = [vp, f64, i32, i32, i64]
     lib.ldpc_hip_mt_frames_multi.argtypes = [vp, f64, i32, i32, i32, f64, i64, vp, vp]
+    lib.ldpc_hip_mt_shard_begin.argtypes = [vp, f64, i32, i32, i64, i32, i32, C.POINTER(C.c_ulonglong)]
+    lib.ldpc_hip_mt_shard_emit.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(i32), vp, C.POINTER(i64)]
+    lib.ldpc_hip_mt_shard_commit.argtypes = [vp, vp, i64, i32, f64, vp, vp]
+    lib.ldpc_hip_mt_shard_abandon.argtypes = [vp]
+    lib.ldpc_hip_mt_shard_abandon.restype = None
     lib.ldpc_hip_multi_mt_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     lib.ldpc_hip_multi_mt_stats.restype = None
     if lib.ldpc_hip_abi_version() != 4:
@@ -370,6 +375,32 @@ class LdpcHip:
                                                lo, hi, info.ctypes.data, its.ctypes.data)
         _check(self.lib, rc, "ldpc_hip_mt_frames_slice")
         return info, its
+
+    # the generator's tape shared out over the ranks of a job, one process per GPU (ldpc_hip_mt_shard_*: the exchanges are the caller's)
+    def mt_shard_begin(self, snr_db, frames, rank, n, modulation=0, punctured_blocks=0):
+        own = C.c_ulonglong()
+        _check(self.lib, self.lib.ldpc_hip_mt_shard_begin(self.h, float(snr_db), int(modulation), int(punctured_blocks), int(frames), int(rank), int(n),
+                                                          C.byref(own)), "ldpc_hip_mt_shard_begin")
+        return own.value
+
+    def mt_shard_emit(self, counts):
+        cnt = np.ascontiguousarray(counts, dtype=np.uint64)
+        found, covered, fdone = C.c_int(), C.c_int(), C.c_longlong()
+        st = np.zeros(624, dtype=np.uint32)
+        _check(self.lib, self.lib.ldpc_hip_mt_shard_emit(self.h, cnt.ctypes.data, C.byref(found), C.byref(covered), st.ctypes.data, C.byref(fdone)),
+               "ldpc_hip_mt_shard_emit")
+        return bool(found.value), bool(covered.value), st, fdone.value
+
+    def mt_shard_commit(self, state, frames_done, maxiter, rows, alpha=0.8):
+        st = np.ascontiguousarray(state, dtype=np.uint32)
+        info = np.empty(max(int(rows), 0), dtype=np.int32)
+        its = np.empty(max(int(rows), 0), dtype=np.int32)
+        _check(self.lib, self.lib.ldpc_hip_mt_shard_commit(self.h, st.ctypes.data, int(frames_done), int(maxiter), float(alpha),
+                                                           info.ctypes.data if rows > 0 else None, its.ctypes.data if rows > 0 else None), "ldpc_hip_mt_shard_commit")
+        return info, its
+
+    def mt_shard_abandon(self):
+        self.lib.ldpc_hip_mt_shard_abandon(self.h)
 
     # ---- host-pointer API (upstream array layout, PCIe inclusive) --------------------------------------
     def decode_host(self, llr, maxiter, decision=0, alpha=0.8, clobber_sp_input=True):

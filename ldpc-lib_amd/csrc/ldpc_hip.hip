@@ -225,6 +225,7 @@ struct ldpc_hip_ctx {
     int32_t *d_scatter = nullptr;         // [N] decoder index of channel bit j
     // exact replay of upstream's noise on the device (ldpc_mt.hpp, ldpc_hip_mt_*)
     ldpc_mt::DeviceState mt;
+    MtShardRound mt_round;                // a round of the shared-out generator whose exchange the caller does (ldpc_hip_mt_shard_*)
     // HIP-event timing of decode launches
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;

@@ -690,3 +690,38 @@ inline void release(DeviceState &m) {
 }
 
 }  // namespace ldpc_mt
+
+// ---- host-side descriptions of a generation round (used by ldpc_mt_api.hpp, ldpc_multi.hpp and, as a member, by ldpc_hip_ctx)
+namespace {
+
+// The round as a whole: how many attempts are on offer and how far the tape reaches (the same for every shard count).
+struct MtPlan {
+    unsigned long long need = 0;   // items wanted
+    long long pos = 0;             // tape index of the first unread word (0..624)
+    long long attempts = 0;        // attempts on offer: tape words pos + 4a .. pos + 4a + 3, a < attempts
+    long long tape_words = 0;      // generated words behind the first 624 (the last 624 of them stay unread: they can become the next state)
+    long long margin = 0;          // attempts by which the position of an item may be off its expectation (8 standard deviations + slack)
+};
+
+// A context's window of the tape: whole sub-streams of 2^ls words on the grid that starts at tape word 624.
+struct MtWindow {
+    int ls = ldpc_mt::kLog2Stride;
+    long long stride = 0, first = 0, S = 0;   // streams [first, first + S)
+    long long xbase = 0, xwords = 0;          // tape index of xraw[0], words in the window
+    long long gen_words = 0;                  // tape words behind the first 624 the window's streams produce (a multiple of 64)
+    long long at_lo = 0, at_hi = 0;           // attempts whose four words all lie inside the window
+};
+
+// ---- one round of the shared-out generator with the exchange done by the CALLER (one process per GPU; ldpc_multi.hpp does the same
+// over the shards of one process).  State between the three calls:
+struct MtShardRound {
+    bool open = false;
+    MtPlan pl;
+    MtWindow w;
+    ldpc_mt::PolarArgs proto;
+    long long frames = 0, row_lo = 0, row_hi = 0, cut_lo = 0, cut_hi = 0;
+    unsigned long long left = 0, own = 0, base0 = 0, limit = 0;
+    int rank = 0, n = 1;
+};
+
+}  // namespace

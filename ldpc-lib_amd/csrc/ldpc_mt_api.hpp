@@ -25,24 +25,6 @@ int mt_prepare(ldpc_hip_ctx *c) {
 // ---- one generation round, in pieces (a single context runs them back to back; ldpc_multi.hpp runs them per shard with the
 // exchange of the accepted-attempt counts in between) -------------------------------------------------------------------------
 
-// The round as a whole: how many attempts are on offer and how far the tape reaches (the same for every shard count).
-struct MtPlan {
-    unsigned long long need = 0;   // items wanted
-    long long pos = 0;             // tape index of the first unread word (0..624)
-    long long attempts = 0;        // attempts on offer: tape words pos + 4a .. pos + 4a + 3, a < attempts
-    long long tape_words = 0;      // generated words behind the first 624 (the last 624 of them stay unread: they can become the next state)
-    long long margin = 0;          // attempts by which the position of an item may be off its expectation (8 standard deviations + slack)
-};
-
-// A context's window of the tape: whole sub-streams of 2^ls words on the grid that starts at tape word 624.
-struct MtWindow {
-    int ls = ldpc_mt::kLog2Stride;
-    long long stride = 0, first = 0, S = 0;   // streams [first, first + S)
-    long long xbase = 0, xwords = 0;          // tape index of xraw[0], words in the window
-    long long gen_words = 0;                  // tape words behind the first 624 the window's streams produce (a multiple of 64)
-    long long at_lo = 0, at_hi = 0;           // attempts whose four words all lie inside the window
-};
-
 inline int mt_log2_stride(long long words) {
     // stream length by the size of the job: the generate kernel is bound by the latency of one wave walking its stream, the jumps
     // by their number -- short streams for small rounds, 2^20 words for the 65536-frame batches
@@ -412,6 +394,115 @@ int ldpc_hip_mt_frames_slice(ldpc_hip_ctx *c, double snr_db, int modulation_type
     if (int rc = set_device(c)) return rc;
     return mt_frames_slice(c, snr_db, modulation_type, punctured_blocks, maxiter, alpha, B, lo, hi, frame_info, iters, nullptr);
 }
+
+int ldpc_hip_mt_shard_begin(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, long long frames, int rank, int n,
+                            unsigned long long *own_count) {
+    using namespace ldpc_mt;
+    if (!c || frames < 1 || n < 1 || rank < 0 || rank >= n || !own_count) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_shard_begin: bad argument");
+    if (frames > mt_frames_per_round(c) || frames > (1 << 16)) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_shard_begin: at most %lld frames per round", mt_frames_per_round(c) < (1 << 16) ? mt_frames_per_round(c) : (long long)(1 << 16));
+    if (int rc = set_device(c)) return rc;
+    MtShardRound &r = c->mt_round;
+    r = MtShardRound();
+    if (int rc = mt_frame_proto(c, snr_db, modulation_type, punctured_blocks, r.proto)) return rc;
+    r.frames = frames; r.rank = rank; r.n = n;
+    r.row_lo = frames * rank / n; r.row_hi = frames * (rank + 1) / n;
+    const long long N = c->N;
+    r.pl = mt_plan(c->mt.pos, (unsigned long long)frames * (unsigned long long)N);
+    auto cut = [&](int i) -> long long {   // attempt index where rank i's stretch is expected to start
+        if (i <= 0) return 0;
+        if (i >= n) return r.pl.attempts;
+        const long long at = (long long)((double)(frames * i / n) * (double)N * 1.2732395447351628);
+        return at < r.pl.attempts ? at : r.pl.attempts;
+    };
+    r.cut_lo = cut(rank); r.cut_hi = cut(rank + 1);
+    *own_count = 0;
+    r.open = true;
+    if (r.cut_lo >= r.cut_hi) { r.w = MtWindow(); return 0; }   // nothing to own (and then no rows either, or the caller falls back)
+    const long long a_lo = r.cut_lo - r.pl.margin, a_hi = r.cut_hi + r.pl.margin;
+    r.w = mt_window(r.pl, r.pl.pos + 4 * (a_lo < 0 ? 0 : a_lo), r.pl.pos + 4 * (a_hi > r.pl.attempts ? r.pl.attempts : a_hi) + MTN);
+    if (int rc = mt_ensure(c, r.w)) return rc;
+    if (int rc = mt_generate(c, r.w, nullptr)) return rc;
+    if (int rc = mt_count(c, r.pl, r.w, r.w.at_lo, r.cut_lo, r.cut_hi, nullptr)) return rc;
+    unsigned long long cnt[2] = {0, 0};
+    HIP_TRY(hipMemcpy(cnt, c->mt.d_counters, sizeof cnt, hipMemcpyDeviceToHost));
+    r.left = cnt[0]; r.own = cnt[1];
+    *own_count = r.own;
+    return 0;
+}
+
+int ldpc_hip_mt_shard_emit(ldpc_hip_ctx *c, const unsigned long long *counts, int *found, int *covered, uint32_t state_next[624], long long *frames_done) {
+    using namespace ldpc_mt;
+    if (!c || !counts || !found || !covered || !state_next || !frames_done) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_shard_emit: bad argument");
+    MtShardRound &r = c->mt_round;
+    if (!r.open) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_shard_emit: no round is open (ldpc_hip_mt_shard_begin first)");
+    if (int rc = set_device(c)) return rc;
+    const unsigned long long N = (unsigned long long)c->N;
+    unsigned long long before = 0, total = 0;
+    for (int i = 0; i < r.n; ++i) { if (i < r.rank) before += counts[i]; total += counts[i]; }
+    r.limit = total < r.pl.need ? total : r.pl.need;
+    r.limit -= r.limit % N;
+    *frames_done = (long long)(r.limit / N);
+    *found = 0;
+    const unsigned long long lo_item = (unsigned long long)r.row_lo * N;
+    unsigned long long hi_item = (unsigned long long)r.row_hi * N;
+    if (hi_item > r.limit) hi_item = r.limit;
+    const bool wants_rows = lo_item < hi_item;
+    *covered = wants_rows ? 0 : 1;
+    // the window must reach from its cut's margin to the next cut (it does unless the tape ended early)
+    if (r.w.S == 0 || r.w.at_lo > r.cut_lo || r.w.at_hi < r.cut_hi) return 0;
+    r.base0 = before - r.left;
+    const long long rows = r.row_hi - r.row_lo;
+    if (rows > 0) { if (int rc = ensure_workspace(c, rows, false)) return rc; }
+    PolarArgs a = r.proto;
+    a.first_frame = c->mt.frames_taken;
+    if (rows > 0) { a.row_lo = r.row_lo; a.row_hi = r.row_hi; a.out = c->w_llr; } else { a.row_lo = 0; a.row_hi = 0; a.out = nullptr; }
+    if (int rc = mt_emit(c, r.pl, r.w, a, r.base0, nullptr)) return rc;
+    if (int rc = mt_finish(c, r.pl, r.w, a, r.base0, (long long)r.limit, nullptr)) return rc;
+    unsigned long long tot[2] = {0, 0};
+    long long endt[2] = {0, 0};
+    HIP_TRY(hipMemcpy(tot, c->mt.d_total, sizeof tot, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(endt, c->mt.d_end_t, sizeof endt, hipMemcpyDeviceToHost));
+    if (endt[1] == 1) {
+        *found = 1;
+        HIP_TRY(hipMemcpy(state_next, c->mt.d_state_next, sizeof(uint32_t) * MTN, hipMemcpyDeviceToHost));
+    }
+    if (wants_rows) *covered = (r.base0 <= lo_item && r.base0 + tot[0] >= hi_item) ? 1 : 0;
+    return 0;
+}
+
+int ldpc_hip_mt_shard_commit(ldpc_hip_ctx *c, const uint32_t state[624], long long frames_done, int maxiter, double alpha, int32_t *frame_info,
+                             int32_t *iters) {
+    using namespace ldpc_mt;
+    if (!c || !state || frames_done < 0) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_shard_commit: bad argument");
+    MtShardRound &r = c->mt_round;
+    if (!r.open) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_shard_commit: no round is open");
+    if (int rc = set_device(c)) return rc;
+    r.open = false;
+    HIP_TRY(hipMemcpy(c->mt.d_state, state, sizeof(uint32_t) * MTN, hipMemcpyHostToDevice));
+    c->mt.pos = 0;
+    const long long first = c->mt.frames_taken;
+    c->mt.frames_taken += frames_done;
+    const long long r_hi = r.row_hi < frames_done ? r.row_hi : frames_done, rows = r_hi - r.row_lo;
+    if (rows <= 0) return 0;
+    if (!frame_info || !iters) return fail(LDPC_HIP_EINVAL, "ldpc_hip_mt_shard_commit: null record arrays");
+    DeviceState &m = c->mt;
+    if (rows > m.cap_rec) {
+        if (m.d_info) (void)hipFree(m.d_info);
+        if (m.d_iters) (void)hipFree(m.d_iters);
+        m.d_info = nullptr; m.d_iters = nullptr; m.cap_rec = 0;
+        HIP_TRY(hipMalloc(&m.d_info, sizeof(int32_t) * (size_t)rows));
+        HIP_TRY(hipMalloc(&m.d_iters, sizeof(int32_t) * (size_t)rows));
+        m.cap_rec = rows;
+    }
+    HIP_TRY(hipMemsetAsync(c->w_counters, 0, sizeof(unsigned long long) * 8, nullptr));
+    if (int rc = ldpc_hip_decode_dev(c, c->w_llr, rows, maxiter, alpha, c->w_hard, m.d_iters, nullptr, nullptr)) return rc;
+    if (int rc = ldpc_hip_count_errors_cw_dev(c, c->w_hard, m.d_iters, first + r.row_lo, rows, m.d_info, c->w_counters, nullptr)) return rc;
+    HIP_TRY(hipMemcpy(frame_info, m.d_info, sizeof(int32_t) * (size_t)rows, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(iters, m.d_iters, sizeof(int32_t) * (size_t)rows, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+void ldpc_hip_mt_shard_abandon(ldpc_hip_ctx *c) { if (c) c->mt_round.open = false; }
 
 int ldpc_hip_mt_frames(ldpc_hip_ctx *c, double snr_db, int modulation_type, int punctured_blocks, int maxiter, double alpha, long long B,
                        int32_t *frame_info, int32_t *iters) {

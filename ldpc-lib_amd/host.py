@@ -11,6 +11,8 @@ std::normal_distribution per sample, after the codeword draws of bp_simulation.c
 counters, BER / FER and the generator state afterwards are upstream's, bit for bit.  With several ranks every rank runs the same
 generator over the whole round and decodes its slice.  The C++ layer in csrc/compat/ does the same for upstream's C++ callers.
 """
+import os
+
 import numpy as np
 
 from .binding import DEC_IMS, DEC_LMS, DEC_MS, DEC_SP, DEC_TASP, LdpcHip, LdpcHipError
@@ -112,6 +114,8 @@ class MtFrameSource:
         self.dec = LdpcHip(decoder_type, H, tailbite_length, device)
         self.n, self.r = self.dec.N, self.dec.R
         self.args = (snr, modulation_type, punctured_blocks, max_iterations, alpha)
+        self.share_tape = os.environ.get("LDPC_HIP_MT_SHARDED", "1") != "0"
+        self.shared_rounds = self.fallback_rounds = 0
         # random_codeword() draws (nh - rh) * M values of next_random_int(0, 2) first, one generator word each (bp_simulation.cpp:512,160-162)
         self.dec.mt_set_state(*mt19937_state(seed, (H.shape[1] - H.shape[0]) * tailbite_length))
 
@@ -128,11 +132,53 @@ class MtFrameSource:
         if frames:
             self.dec.mt_llr(snr, frames, modulation=mod, punctured_blocks=punct, skip=True)
 
+    group = None   # torch.distributed group of the job (bp_simulation sets it)
+
     def round(self, total, lo, hi):
+        """records of frames [lo, hi) of the next `total` frames.  In a torch.distributed job with equal contiguous slices the ranks
+        share the generator's tape out (ldpc_hip_mt_shard_*: every rank makes ~1/n of the words; three small exchanges per round);
+        otherwise -- one rank, a round beyond 65536 frames, or an estimate that failed -- every rank runs the whole generator."""
         import torch
+        import torch.distributed as dist
         snr, mod, punct, maxit, alpha = self.args
-        info, its = self.dec.mt_frames(snr, maxit, total, modulation=mod, punctured_blocks=punct, alpha=alpha, lo=lo, hi=hi)
+        group = self.group
         dev = torch.device("cuda", self.dec.device)   # device tensors: the record exchange may run over RCCL
+        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank(group) if world > 1 else 0
+        shared = (world > 1 and self.share_tape and total <= 65536 and total * self.n <= (1 << 27)
+                  and lo == total * rank // world and hi == total * (rank + 1) // world)
+        if shared:
+            host = torch.device("cpu")
+
+            def gather(vals):   # a few integers per rank, through the host (gloo) or the device (RCCL)
+                use_dev = dist.get_backend(group) == "nccl"
+                t = torch.tensor(vals, dtype=torch.int64, device=dev if use_dev else host)
+                out = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(out, t, group=group)
+                return [o.cpu().tolist() for o in out]
+
+            own = self.dec.mt_shard_begin(snr, total, rank, world, modulation=mod, punctured_blocks=punct)
+            counts = [g[0] for g in gather([own])]
+            found, covered, st, fdone = self.dec.mt_shard_emit(counts)
+            flags = gather([int(found), int(covered)])
+            owner = next((r for r, f in enumerate(flags) if f[0]), None)
+            if owner is not None and all(f[1] for f in flags):
+                use_dev = dist.get_backend(group) == "nccl"
+                t = torch.from_numpy(st.astype(np.int64)).to(dev if use_dev else host)
+                dist.broadcast(t, src=dist.get_global_rank(group, owner) if group is not None else owner, group=group)
+                state = t.cpu().numpy().astype(np.uint32)
+                rows = max(min(hi, fdone) - lo, 0)
+                info, its = self.dec.mt_shard_commit(state, fdone, maxit, rows, alpha=alpha)
+                self.shared_rounds += 1
+                if fdone == total:
+                    return torch.from_numpy(info).to(dev), torch.from_numpy(its).to(dev)
+                # a short round (the number of accepted attempts is random; 8 sigma): the rest of the frames the plain way
+                i2, t2 = self.dec.mt_frames(snr, maxit, total - fdone, modulation=mod, punctured_blocks=punct, alpha=alpha,
+                                            lo=max(lo - fdone, 0), hi=max(hi - fdone, 0))
+                return torch.from_numpy(np.concatenate([info, i2])).to(dev), torch.from_numpy(np.concatenate([its, t2])).to(dev)
+            self.dec.mt_shard_abandon()
+            self.fallback_rounds += 1
+        info, its = self.dec.mt_frames(snr, maxit, total, modulation=mod, punctured_blocks=punct, alpha=alpha, lo=lo, hi=hi)
         return torch.from_numpy(info).to(dev), torch.from_numpy(its).to(dev)
 
     def close(self):
@@ -160,6 +206,8 @@ def bp_simulation(H, tailbite_length, max_iterations, n_frame_errors, n_experime
         src = source if source is not None else GpuFrameSource(H, tailbite_length, decoder_type, max_iterations, snr,
                                                                modulation_type, punctured_blocks, seed, device, alpha)
     exact = isinstance(src, MtFrameSource)
+    if exact:
+        src.group = group
     n, r = src.n, src.r
     state = {"nse": 0, "nde": 0, "nue": 0, "experiment": 0, "sum_abs_iters": 0}
     base, stop = 0, False
@@ -188,6 +236,8 @@ def bp_simulation(H, tailbite_length, max_iterations, n_frame_errors, n_experime
         if exact:
             snap = src.snapshot()                     # (624 words, next index): what upstream's `generator` holds afterwards
             state["generator"] = snap[:2] if isinstance(snap, tuple) else snap
+            state["tape_shared_rounds"] = getattr(src, "shared_rounds", 0)
+            state["tape_fallback_rounds"] = getattr(src, "fallback_rounds", 0)
     finally:
         if source is None:
             src.close()

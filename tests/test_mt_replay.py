@@ -336,20 +336,25 @@ import ldpc_lib_amd
 from ldpc_testlib import load_base_matrix, relift
 from test_mt_replay import _EXACT_CASES, raw_after
 dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
-out = []
+out, shared = [], []
 for dec_id, M, snr, maxit, n_fe, n_exp, ref, seed in _EXACT_CASES:
     H = relift(load_base_matrix(), M)
     ber, fer, st = ldpc_lib_amd.bp_simulation(H, M, maxit, n_fe, n_exp, snr, ref, decoder_type=dec_id, exact_seed=seed, batch=700, return_state=True)
     out.append([st["nse"], st["nde"], st["nue"], st["experiment"], st["sum_abs_iters"], ber.hex(), fer.hex(), int(raw_after(*st["generator"], 0, 1)[0])])
+    shared.append([st["tape_shared_rounds"], st["tape_fallback_rounds"]])
 print("RESULT", dist.get_rank(), json.dumps(out))
+print("SHARED", dist.get_rank(), json.dumps(shared))
 dist.destroy_process_group()
 """
 
 
 @pytest.mark.gpu
-def test_two_ranks_exact_replay(L, torch):
-    """one process per GPU (here: two processes on the one GPU, gloo for the records): every rank runs the same generator over the
-    whole round and decodes its slice -- both must report the sequential loop's counters, doubles and generator state."""
+@pytest.mark.parametrize("world,share", [(2, "1"), (3, "1"), (2, "0")])
+def test_two_ranks_exact_replay(L, torch, world, share):
+    """one process per GPU (here: two or three processes on the one GPU, gloo for the exchanges): the ranks share the generator's tape
+    out (ldpc_hip_mt_shard_begin / emit / commit: counts all-gathered, the end state broadcast) or -- LDPC_HIP_MT_SHARDED=0 -- every
+    rank runs the whole generator; either way every rank must report the sequential loop's counters, doubles and generator state,
+    and in the first case every round must have run shared, none fallen back."""
     import json
     import socket
     import subprocess
@@ -363,8 +368,9 @@ def test_two_ranks_exact_replay(L, torch):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   LDPC_HIP_MT_SHARDED=share)
         procs.append(subprocess.Popen([sys.executable, "-c", _EXACT_RANK_WORKER.format(root=root)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -372,6 +378,11 @@ def test_two_ranks_exact_replay(L, torch):
     for o in outs:
         line = [ln for ln in o.splitlines() if ln.startswith("RESULT")][0]
         assert json.loads(line.split(" ", 2)[2]) == want
+        sh = json.loads([ln for ln in o.splitlines() if ln.startswith("SHARED")][0].split(" ", 2)[2])
+        if share == "1":
+            assert all(a > 0 and b == 0 for a, b in sh), sh
+        else:
+            assert all(a == 0 for a, b in sh), sh
 
 
 @pytest.mark.gpu
