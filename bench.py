@@ -317,23 +317,128 @@ def abi_multi_leg(n, steps, warmup, frames):
         }
 
 
-def run_abi_multi_child(args, timeout=900):
-    """the abi_multi leg in a fresh child process (this one may hold a torch.distributed rank's GPU state, or -- the launcher --
-    must never touch the GPU); returns its JSON or {"error": ...}"""
+def run_abi_multi_child(args, timeout=900, leg="abi_multi"):
+    """the abi_multi (or exact_ranks) leg in a fresh child process (this one may hold a torch.distributed rank's GPU state, or -- the
+    launcher -- must never touch the GPU); returns its JSON or {"error": ...}"""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
                                                            "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, os.path.abspath(__file__), "--leg", "abi_multi", "--gpus", str(args.gpus), "--steps", str(args.steps),
-           "--warmup", str(args.warmup), "--frames", str(args.frames)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", leg, "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--frames", str(args.frames), "--backend", args.backend]
     try:
         p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         if p.returncode != 0 or not lines:
-            return {"error": f"abi_multi leg exited with {p.returncode}", "stdout_tail": p.stdout[-500:]}
+            return {"error": f"{leg} leg exited with {p.returncode}", "stdout_tail": p.stdout[-500:]}
         return json.loads(lines[-1])
     except Exception as ex:
         return {"error": repr(ex)}
+
+
+EXACT_RANKS_ROUND = 65536   # global frames per round: the tape of one round is shared out over the ranks
+
+
+def exact_ranks_worker(args):
+    """one rank of the exact_ranks leg: host.bp_simulation(exact_seed=1) in a torch.distributed job, the generator's tape of every
+    65536-frame round shared out over the ranks (ldpc_hip_mt_shard_*), every rank decoding its 1/N slice.  Strong scaling by
+    construction (the round is the reference loop's, not ours to grow).  Counters and the end state of the generator are printed:
+    they must not depend on N."""
+    import zlib
+
+    import torch
+    import torch.distributed as dist
+
+    import ldpc_lib_amd
+    from ldpc_lib_amd import host
+    from ldpc_testlib import load_base_matrix, relift
+    world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.exit(f"bench.py exact_ranks rank {rank}/{world}: no GPU visible")
+    backend = args.backend if world <= ndev else "gloo"   # fewer GPUs than ranks: a rehearsal, ranks share devices
+    local %= ndev
+    torch.cuda.set_device(local)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    H = relift(load_base_matrix(), M)
+    rounds = max(4, min(args.steps, 16))
+    per_rank = EXACT_RANKS_ROUND // world   # N not a power of two: one short extra round, a roll-back inside it
+    src = host.MtFrameSource(H, M, DEC_MS, MAXITER, OPER_SNR, 0, 0, 1, local, ALPHA)
+    try:
+        def run(k):
+            return ldpc_lib_amd.bp_simulation(H, M, MAXITER, 1 << 40, k * EXACT_RANKS_ROUND - 1, OPER_SNR, 1.0, decoder_type=DEC_MS,
+                                              batch=per_rank, device=local, alpha=ALPHA, return_state=True, source=src)
+        run(2)                                                 # warm-up: buffers, jump polynomials, communicator
+        src.dec.mt_set_state(*host.mt19937_state(1, (H.shape[1] - H.shape[0]) * M))
+        src.dec.mt_set_frame_index(0)
+        src.shared_rounds = src.fallback_rounds = 0
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        ber, fer, st = run(rounds)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if world > 1:
+            if backend == "nccl":
+                el = el.cuda()
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        el = float(el.item())
+    finally:
+        src.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        words, pos = st["generator"]
+        print(json.dumps({
+            "what": "host.bp_simulation(exact_seed=1), one process per GPU: per 65536-frame round every rank makes ~1/N of the generator's "
+                    "tape (ldpc_hip_mt_shard_begin/emit/commit; two all-gathers of a few integers + one 2.5 KB broadcast), decodes its "
+                    "1/N of the frames, and the 8-byte records are all-gathered; strong scaling, results independent of N",
+            "value": st["experiment"] / el, "unit": "frames/s", "n_gpus": world, "backend": backend if world > 1 else None,
+            "rounds": rounds, "frames_per_round": per_rank * world, "ms_per_round": el / rounds * 1e3, "ebn0_db": OPER_SNR,
+            "frames": st["experiment"], "errored_frames": st["nde"], "bit_errors": st["nse"], "sum_iterations": st["sum_abs_iters"],
+            "generator_state_crc32": zlib.crc32(words.tobytes()) & 0xffffffff, "generator_next_index": int(pos),
+            "tape_shared_rounds": st["tape_shared_rounds"], "tape_fallback_rounds": st["tape_fallback_rounds"]}))
+
+
+def exact_ranks_leg(args, timeout=420):
+    """launcher of the exact_ranks leg: a process without GPU state starts the N ranks, waits for them with a deadline and relays
+    rank 0's line; on any failure the ranks it started are killed and the error is the result"""
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", "exact_ranks", "--spawned", "--gpus", str(n), "--steps", str(args.steps),
+           "--backend", args.backend]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    deadline, failed = time.time() + timeout, None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = f"rank {r} exited with {p.returncode}"
+        if time.time() > deadline:
+            failed = "timeout"
+        time.sleep(0.1)
+    if failed is not None:
+        for p in procs:   # exactly the processes started above
+            if p.poll() is None:
+                p.kill()
+        return {"error": failed}
+    lines = [ln for ln in procs[0].stdout.read().splitlines() if ln.startswith("{")]
+    return json.loads(lines[-1]) if lines else {"error": "rank 0 printed no result line"}
 
 
 def launch_ranks(args):
@@ -388,6 +493,8 @@ def launch_ranks(args):
     out = json.loads(lines[-1])
     out["launcher"] = "bench.py (parent process without GPU state started one fresh process per rank)"
     out["abi_multi"] = run_abi_multi_child(args)
+    if not args.no_extras:
+        out["exact_replay_ranks"] = exact_ranks_leg(args)
     print(json.dumps(out))
     return 0
 
@@ -403,12 +510,19 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI, the measured configuration); gloo only rehearses the N>1 code path on a box "
                          "with fewer GPUs than ranks (ranks then share devices and the counters are reduced on the host)")
-    ap.add_argument("--leg", default=None, choices=["abi_multi"], help="internal: run only the C-ABI multi-device leg and print its JSON")
+    ap.add_argument("--leg", default=None, choices=["abi_multi", "exact_ranks"],
+                    help="internal: run only the C-ABI multi-device leg / the rank-sharded exact-replay leg and print its JSON")
     ap.add_argument("--spawned", action="store_true", help="internal: this rank was started by bench.py itself (the parent adds the abi_multi leg)")
     args = ap.parse_args()
 
     if args.leg == "abi_multi":
         print(json.dumps(abi_multi_leg(args.gpus, args.steps, args.warmup, args.frames)))
+        return
+    if args.leg == "exact_ranks":
+        if args.spawned:
+            exact_ranks_worker(args)
+        else:
+            print(json.dumps(exact_ranks_leg(args)))
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
@@ -622,11 +736,14 @@ def main():
             out["abi_multi"] = abi_multi_leg(1, max(3, min(args.steps, 10)), 1, B)
         except Exception as ex:
             out["abi_multi"] = {"error": repr(ex)}
+        out["exact_replay_ranks"] = run_abi_multi_child(args, timeout=480, leg="exact_ranks")   # N = 1: the figures the N > 1 lines must repeat
     elif world > 1 and not args.spawned:
         # started by an external launcher: the other ranks are on their way out; a fresh child process (never this one re-executed)
         # opens all N GPUs behind the C-ABI
         torch.cuda.empty_cache()
         out["abi_multi"] = run_abi_multi_child(args)
+        if not args.no_extras:
+            out["exact_replay_ranks"] = run_abi_multi_child(args, timeout=480, leg="exact_ranks")
     print(json.dumps(out))
 
 

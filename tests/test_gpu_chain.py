@@ -458,6 +458,27 @@ def test_bench_gpus_2_runs_without_a_launcher(L):
     assert abs(abi["fer"] - line["config"]["fer"]) < 0.01 and abi["mean_iters_per_frame"] > 49.9   # the same workload: 0 dB, all iterations
 
 
+@pytest.mark.gpu
+def test_bench_exact_ranks_leg_is_independent_of_the_rank_count(L):
+    """bench.py's exact_replay_ranks leg (host.bp_simulation(exact_seed=1) as a one-process-per-GPU job, the generator's tape shared
+    out over the ranks): three ranks on this box's one GPU (gloo) must report the counters and the generator end state of one rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    lines = {}
+    for n in (1, 3):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--leg", "exact_ranks", "--gpus", str(n), "--steps", "4"], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+        lines[n] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        assert "error" not in lines[n], lines[n]
+    same = ("frames", "errored_frames", "bit_errors", "sum_iterations", "generator_state_crc32", "generator_next_index")
+    assert lines[1]["frames"] == 4 * 65536 and [lines[1][k] for k in same] == [lines[3][k] for k in same]
+    assert lines[3]["tape_shared_rounds"] >= 4 and lines[3]["tape_fallback_rounds"] == 0 and lines[1]["tape_shared_rounds"] == 0
+
+
 def test_multi_gpu_c_example_runs(L, tmp_path):
     """examples/simulate_multi.c end to end (every GPU of the box, RCCL when there is more than one... one here): random codewords,
     16-QAM, block interleaver; FER in the range the Python route measures for the same point."""
