@@ -486,3 +486,54 @@ def test_sharded_generation_with_the_whole_chain_and_roll_forward(L, torch, monk
                 assert np.array_equal(got[k][0], want[k][0]) and np.array_equal(got[k][1], want[k][1]), (n, k)
             assert np.array_equal(got[3][0], want[3][0]) and got[3][1] == want[3][1]
             assert m.mt_stats()[1] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dec_id,M,snr,n,rounds,mod,punct", [
+    (MS_DEC, 64, 2.0, 2, (4000, 4001, 7), 0, 0), (MS_DEC, 64, 1.5, 3, (65536, 1000, 2), 0, 0), (LMS_DEC, 126, 1.7, 5, (2500, 333), 0, 2),
+    (MS_DEC, 1, 4.0, 8, (60000, 9), 0, 0), (SP_DEC, 64, 2.5, 4, (3000, 3000), 1, 1)])
+def test_shard_protocol_through_the_c_abi(L, torch, dec_id, M, snr, n, rounds, mod, punct):
+    """ldpc_hip_mt_shard_begin / _emit / _commit with n contexts of this process in the role of the ranks and the three exchanges
+    done by hand: per round at least one rank finds the end state (all that do agree), every rank is covered, the concatenated records equal one context's
+    ldpc_hip_mt_frames and so does the generator afterwards.  Rounds with fewer frames than ranks leave some ranks without frames.
+    One abandoned round in between (nothing may have moved)."""
+    H = relift(load_base_matrix(), M)
+    key, pos = seeded_state(11)
+    with L.LdpcHip(dec_id, H, M) as one:
+        one.mt_set_state(key, pos)
+        want = [one.mt_frames(snr, 20, f, modulation=mod, punctured_blocks=punct) for f in rounds]
+        want_state = one.mt_get_state()
+    ranks = [L.LdpcHip(dec_id, H, M) for _ in range(n)]
+    try:
+        for d in ranks:
+            d.mt_set_state(key, pos)
+        for k, frames in enumerate(rounds):
+            if k == 1:   # a round begun and given up: state and frame index as before
+                for r, d in enumerate(ranks):
+                    d.mt_shard_begin(snr, frames, r, n, modulation=mod, punctured_blocks=punct)
+                    d.mt_shard_abandon()
+            counts = [d.mt_shard_begin(snr, frames, r, n, modulation=mod, punctured_blocks=punct) for r, d in enumerate(ranks)]
+            outs = [d.mt_shard_emit(counts) for d in ranks]
+            assert any(o[0] for o in outs) and all(o[1] for o in outs), [(o[0], o[1], o[3]) for o in outs]
+            owner = [o[0] for o in outs].index(True)   # windows overlap in a short round: several ranks may hold the last item
+            assert all(np.array_equal(o[2], outs[owner][2]) for o in outs if o[0])
+            fdone = outs[owner][3]
+            assert all(o[3] == fdone for o in outs) and 0 < fdone <= frames
+            info, its = [], []
+            for r, d in enumerate(ranks):
+                lo, hi = frames * r // n, frames * (r + 1) // n
+                a, b = d.mt_shard_commit(outs[owner][2], fdone, 20, max(min(hi, fdone) - lo, 0))
+                info.append(a)
+                its.append(b)
+            info, its = np.concatenate(info), np.concatenate(its)
+            if fdone < frames:   # a short round: the remainder the plain way, on every rank
+                rest = [d.mt_frames(snr, 20, frames - fdone, modulation=mod, punctured_blocks=punct) for d in ranks]
+                info, its = np.concatenate([info, rest[0][0]]), np.concatenate([its, rest[0][1]])
+            assert np.array_equal(info, want[k][0]) and np.array_equal(its, want[k][1]), (k, frames)
+        for d in ranks:
+            st = d.mt_get_state()
+            assert np.array_equal(st[0], want_state[0]) and st[1] == want_state[1]
+            assert d.mt_frame_index() == sum(rounds)
+    finally:
+        for d in ranks:
+            d.close()
