@@ -25,7 +25,7 @@ LDPC_AOT_DECLARE(ims_spec_appendix_c_m64_kernel, 64, 3)
 LDPC_AOT_DECLARE(ims_spec_appendix_c_m126_kernel, 128, 2)
 LDPC_AOT_DECLARE(lms_spec_appendix_c_m64_kernel, 64, 2)
 LDPC_AOT_DECLARE(lms_spec_appendix_c_m512_kernel, 512, 2)
-LDPC_AOT_DECLARE(sp_spec_appendix_c_m64_kernel, 256, 2)
+LDPC_AOT_DECLARE(sp_spec_appendix_c_m64_kernel, 512, 4)
 LDPC_AOT_DECLARE(bp_spec_appendix_c_m64_kernel, 512, 4)
 LDPC_AOT_DECLARE(asp_spec_appendix_c_m64_kernel, 512, 4)
 LDPC_AOT_DECLARE(tasp_spec_appendix_c_m64_kernel, 64, 1)

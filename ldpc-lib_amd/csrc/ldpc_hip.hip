@@ -132,7 +132,7 @@ const AotInstance kAot[] = {
     {LDPC_HIP_IMS_DEC, (const void *)ims_spec_appendix_c_m126_kernel, 128, "ims_spec_appendix_c_m126_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM126>},
     {LDPC_HIP_LMS_DEC, (const void *)lms_spec_appendix_c_m64_kernel, 64, "lms_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_LMS_DEC, (const void *)lms_spec_appendix_c_m512_kernel, 512, "lms_spec_appendix_c_m512_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM512>},
-    {LDPC_HIP_SP_DEC, (const void *)sp_spec_appendix_c_m64_kernel, 256, "sp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
+    {LDPC_HIP_SP_DEC, (const void *)sp_spec_appendix_c_m64_kernel, 64 * ldpc_spec::kSpBodyWaves, "sp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_BP_DEC, (const void *)bp_spec_appendix_c_m64_kernel, 512, "bp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_ASP_DEC, (const void *)asp_spec_appendix_c_m64_kernel, 512, "asp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_TASP_DEC, (const void *)tasp_spec_appendix_c_m64_kernel, 64, "tasp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},

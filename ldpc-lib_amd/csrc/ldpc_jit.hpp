@@ -119,9 +119,8 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
     static std::mutex mu;
     static std::map<std::string, Kernel> &cache = *new std::map<std::string, Kernel>();   // never destroyed: a background compile may outlive main()
     const std::string code = code_struct(rows, nh, M);
-    const bool eight_waves = std::string(body) == "asp_body" || std::string(body) == "bp_body";  // 8 waves per frame, 2 frames per CU
-    const bool four_waves = std::string(body) == "sp_body";                                       // 4 waves per frame, 2 frames per CU
-    const int threads = eight_waves ? 512 : four_waves ? 256 : std::string(body) == "ms_chunk_body" ? 64 : ((M + 63) / 64) * 64;
+    const bool eight_waves = std::string(body) == "sp_body" || std::string(body) == "asp_body" || std::string(body) == "bp_body";  // 8 waves per frame, 2 frames per CU
+    const int threads = eight_waves ? 512 : std::string(body) == "ms_chunk_body" ? 64 : ((M + 63) / 64) * 64;
     const std::string key = std::to_string(device) + "|" + body + "|" + code;
     // the lock covers the process cache only: a compile takes seconds and must not hold up other contexts
     auto lookup = [&]() -> const Kernel * {

@@ -289,7 +289,9 @@ __device__ __attribute__((aligned(16))) const unsigned long long kLogData[274] =
 };
 template <class Tab>
 __device__ __forceinline__ double log_glibc_t(double x, Tab T) {
-    auto D = [&](int i) { return __longlong_as_double((long long)T[i]); };
+    // the polynomial coefficients are compile-time constants whatever table pointer the look-up below uses (bp_body passes a copy in
+    // LDS: through it they were 11 LDS reads per evaluation)
+    auto D = [&](int i) { return __longlong_as_double((long long)kLogData[i]); };
     unsigned long long ix = (unsigned long long)__double_as_longlong(x);
     const u32 top = (u32)(ix >> 48);
     const unsigned long long LO = 0x3fee000000000000ull /* 1.0 - 0x1p-4 */, HI = 0x3ff1090000000000ull /* 1.0 + 0x1.09p-4 */;
@@ -1262,11 +1264,13 @@ __device__ __forceinline__ void lms_small_body(const SpecArgs &a) {
 #define LDPC_SP_WAVES 8           // (macros: tools/ab_sp.hip builds the variants)
 #endif
 #ifndef LDPC_SP_BODY_WAVES
-#define LDPC_SP_BODY_WAVES 4
+#define LDPC_SP_BODY_WAVES 8
 #endif
 constexpr int kSpWaves = LDPC_SP_WAVES;       // wavefronts per frame of the asp / bp bodies (two frames per CU at 4 waves per SIMD, <= 128 VGPRs)
-constexpr int kSpBodyWaves = LDPC_SP_BODY_WAVES;   // sp_body: four waves per frame at 2 waves per SIMD (256 VGPRs, no spills) is 9-13 % faster than eight with
-                                  // 101 spilled registers (tools/ab_sp.hip, profiles/r02_sp_variants.txt); asp_body gains nothing, bp_body loses 25 %
+constexpr int kSpBodyWaves = LDPC_SP_BODY_WAVES;   // sp_body: eight too since round 3.  In round 2 four waves per frame at 2 waves per SIMD (251 VGPRs, no spills) beat eight
+                                  // with 101 spilled registers by 9-13 % (profiles/r02_sp_variants.txt).  The registers were rotated LDS addresses of the
+                                  // unrolled phases, hoisted out of the iteration loop; with the lane id laundered once per iteration (see the loops) eight
+                                  // waves need 126 registers, spill nothing and are 3.5 % (0 dB) to 9 % (2 dB) faster than four (profiles/r03_sp_family_ab.txt)
 
 template <class C, int WAVES = kSpWaves>
 struct SpView {  // column view of the code + static work split, all computed at compile time
@@ -1313,7 +1317,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
     char *const sb = zzb + (size_t)NE * M * 8;                              // s[j][n]
     unsigned char *const hb = reinterpret_cast<unsigned char *>(sb + (size_t)R * 8);  // [N]
     int *const flag = reinterpret_cast<int *>(hb + ((N + 15) & ~15));
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // lanes beyond the lifting in the last 64-lane chunk of a circulant sit out
     auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
@@ -1361,6 +1365,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
     bool conv = !vote(syndrome_fail());                                              // :1964-2002
     if (conv) res = 0;
     for (int iter = 0; !conv && iter < a.maxiter; ++iter) {
+        asm volatile("" : "+v"(lane));   // per iteration: keeps the rotated LDS addresses of the unrolled phases out of the loop-invariant set (registers)
         // ---- phase A
         static_for<0, NH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u], CW = V.cw[k];
@@ -1607,7 +1612,7 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
     char *const stb = reinterpret_cast<char *>(lds);                         // state[e][n] at e*M*8 + n*8
     unsigned char *const hb = reinterpret_cast<unsigned char *>(stb + (size_t)NE * M * 8);  // [N] soft_out > 0.5
     int *const flag = reinterpret_cast<int *>(hb + ((N + 15) & ~15));
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // lanes beyond the lifting in the last 64-lane chunk of a circulant sit out
     auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
@@ -1659,6 +1664,7 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
     bool fail = vote(syndrome_fail());                                        // :2393-2399
     int steps = 0;
     while (fail && steps < a.maxiter) {
+        asm volatile("" : "+v"(lane));   // per iteration: keeps the rotated LDS addresses of the unrolled phases out of the loop-invariant set (registers)
         // ---- phase 1: check nodes
         static_for<0, RH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH, RW = C::RW[j];
@@ -1743,6 +1749,30 @@ __device__ __forceinline__ void asp_body(const SpecArgs &a) {
 // exp() / log() are evaluated with glibc's own algorithms (exp_glibc, log_glibc above), so the a-posteriori LLRs equal the CPU
 // reference's bit for bit like everything else (round 1 used ocml's and matched to rtol 1e-5).
 // ---------------------------------------------------------------------------------------------------------------
+// The column phases (A and B) as DATA: what wave w does is read with scalar loads at run time.  Unrolled like the row phases (round 2)
+// they were 224 inlined exp() + log() pairs = 300 KB of code against a 64 KB instruction cache that two CUs share, 205 spilled
+// registers, 40 s of compile time.  As a loop over the unit's edge list the two phases are UMAX (= 4) copies of one exp / log pair
+// each: 39 KB, no scratch, 4 s to compile, 25 % less time per launch (profiles/r03_sp_family_ab.txt).
+template <class C>
+struct BpPlan {
+    static constexpr int CH = (C::M + 63) / 64, W = kSpWaves, UMAX = SpView<C>{}.units_max, RH = C::RH;
+    struct Edge { int zoff, boff, jm, rot; };   // ZZ[e][0] in bytes, BB[e][0], j*M, shift
+    int k[W][UMAX] = {}, ch[W][UMAX] = {}, cw[W][UMAX] = {};   // unit q of wave w: block column (-1: none), 64-lane chunk, column weight
+    Edge edge[W][UMAX][RH] = {};
+    constexpr BpPlan() {
+        constexpr SpView<C> V{};
+        for (int w = 0; w < W; ++w)
+            for (int q = 0; q < UMAX; ++q) k[w][q] = -1;
+        for (int u = 0; u < C::NH * CH; ++u) {
+            const int w = V.col_wave[u], q = V.col_slot[u], kk = u / CH;
+            k[w][q] = kk; ch[w][q] = u % CH; cw[w][q] = V.cw[kk];
+            for (int x = 0; x < V.cw[kk]; ++x) edge[w][q][x] = Edge{V.ce[kk][x] * C::M * 8, V.ce[kk][x] * C::M, V.cj[kk][x] * C::M, V.cc[kk][x]};
+        }
+    }
+};
+template <class C>
+__device__ const BpPlan<C> kBpPlan{};
+
 template <class C>
 __device__ __forceinline__ void bp_body(const SpecArgs &a) {
     constexpr SpView<C> V{};
@@ -1765,21 +1795,23 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
     }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // lanes beyond the lifting in the last 64-lane chunk of a circulant sit out
     auto lane_ok = [&](auto CHI) { constexpr int c = decltype(CHI)::value; return (c * 64 + 64 <= M) || (c * 64 + lane < M); };
     const long long fr = a.frame_idx ? a.frame_idx[blockIdx.x] : (long long)blockIdx.x;
+    const BpPlan<C> &P = kBpPlan<C>;
 
     FrameVote fvote;
     fvote.init(flag);
     auto vote = [&](bool fail) -> bool { return fvote(fail); };
     u64 left[RUMAX];   // syndrome bits of this wave's row units as last computed (what upstream leaves in st->syndr)
     static_for<0, RUMAX>([&](auto Q) { left[decltype(Q)::value] = 0ull; });
-    auto syndrome_fail = [&](bool with_stale) -> bool {
+    // `ln` = the lane id, laundered once per iteration: the rotated LDS addresses of the unrolled row phases are loop invariant, and
+    // hoisted out of the iteration loop they are ~100 live registers of which half go to scratch
+    auto syndrome_fail = [&](bool with_stale, int ln) -> bool {
         bool f = false;
         static_for<0, RH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
             if (wave == u % kSpWaves && lane_ok(IC<ch>{})) {
-                const int n = ch * 64 + lane;
+                const int n = ch * 64 + ln;
                 unsigned sy = 0;
                 if (with_stale && a.stale) sy = (u32)(reinterpret_cast<const u64 *>(a.stale)[fr * (RH * CH) + u] >> lane) & 1u;
                 static_for<0, C::RW[j]>([&](auto S) {
@@ -1793,24 +1825,30 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
         });
         return f;
     };
+    // this wave's unit q: (block column or -1, variable index of this lane, lane takes part, column weight) -- wave-uniform but for t
+    auto unit = [&](int q, int &k, int &t, int &cw) -> bool {
+        k = P.k[wave][q];
+        const int ch = P.ch[wave][q];
+        cw = P.cw[wave][q];
+        t = ch * 64 + lane;
+        return k >= 0 && (M % 64 == 0 || t < M);
+    };
 
     double yd[UMAX], so[UMAX];
-    static_for<0, UMAX>([&](auto Q) { yd[decltype(Q)::value] = 0.0; so[decltype(Q)::value] = 0.0; });
-    static_for<0, NH * CH>([&](auto U) {
-        constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
-        if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
-            const int t = ch * 64 + lane;
+    static_for<0, UMAX>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        int k, t, cw;
+        yd[q] = so[q] = 0.0;
+        if (unit(q, k, t, cw)) {
             const double y = at_least(at_most(a.llr[fr * N + k * M + t], 20.0), -20.0);   // :1738 INPUT_LIMIT
             yd[q] = so[q] = y;
             hb[k * M + t] = y < 0;
-            static_for<0, V.cw[k]>([&](auto X) {                                    // :1731-1733
-                *reinterpret_cast<double *>(zzb + (size_t)V.ce[k][decltype(X)::value] * M * 8 + t * 8) = 0.0;
-            });
+            for (int x = 0; x < cw; ++x) *reinterpret_cast<double *>(zzb + P.edge[wave][q][x].zoff + t * 8) = 0.0;   // :1731-1733
         }
     });
     __syncthreads();
 
-    bool fail = vote(syndrome_fail(true));                                          // :1742-1766
+    bool fail = vote(syndrome_fail(true, lane));                                          // :1742-1766
     // Re-decode pass of the frame chain (frame_idx given, ldpc_hip.hip): the stale syndrome only enters this input check.  If the
     // check fails now and failed in the earlier pass too (that pass returned non-zero: it iterated), every later step is the
     // same as before -- the earlier outputs stand, nothing to redo.  Only a frame that is a codeword at the input (earlier
@@ -1818,18 +1856,22 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
     if (a.frame_idx && fail && a.iters && a.iters[fr] != 0) return;
     int iter = 0;
     while (fail && iter < a.maxiter) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
         // ---- A: variable-node activation
-        static_for<0, NH * CH>([&](auto U) {
-            constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
-            if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
-                const int t = ch * 64 + lane;
-                static_for<0, V.cw[k]>([&](auto X) {
-                    constexpr int e = V.ce[k][decltype(X)::value];
-                    double *z = reinterpret_cast<double *>(zzb + (size_t)e * M * 8 + t * 8);
-                    const double A = exp_glibc_wide(so[q] - *z, etab);
+        static_for<0, UMAX>([&](auto Q) {   // UMAX copies of the edge loop (so[q] in registers); one copy with so[] picked by selects is 5 % slower
+            constexpr int q = decltype(Q)::value;
+            int k, t, cw;
+            if (unit(q, k, t, cw)) {
+                const double soq = so[q];
+#pragma unroll 1
+                for (int x = 0; x < cw; ++x) {
+                    const typename BpPlan<C>::Edge ed = P.edge[wave][q][x];
+                    double *z = reinterpret_cast<double *>(zzb + ed.zoff + t * 8);
+                    const double A = exp_glibc_wide(soq - *z, etab);
                     *z = log_glibc_t(fabs((A - 1) / (A + 1)), ltab);
-                    bbb[e * M + t] = A < 1;
-                });
+                    bbb[ed.boff + t] = A < 1;
+                }
             }
         });
         __syncthreads();
@@ -1837,7 +1879,7 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
         static_for<0, RH * CH>([&](auto U) {
             constexpr int u = decltype(U)::value, j = u / CH, ch = u % CH;
             if (wave == u % kSpWaves && lane_ok(IC<ch>{})) {
-                const int n = ch * 64 + lane;
+                const int n = ch * 64 + ln;
                 double s = 0.0;
                 unsigned bs = 0;
                 static_for<0, C::RW[j]>([&](auto S) {
@@ -1852,28 +1894,29 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
         });
         __syncthreads();
         // ---- B: check-node activation seen from the variable, a-posteriori sums
-        static_for<0, NH * CH>([&](auto U) {
-            constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
-            if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) {
-                const int t = ch * 64 + lane;
+        static_for<0, UMAX>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            int k, t, cw;
+            if (unit(q, k, t, cw)) {
                 double soft = yd[q];                                                  // :1834
-                static_for<0, V.cw[k]>([&](auto X) {
-                    constexpr int x = decltype(X)::value, e = V.ce[k][x], j = V.cj[k][x];
-                    int nn = t - V.cc[k][x]; if (nn < 0) nn += M;                     // rotate by m - circ (:1847)
-                    double *z = reinterpret_cast<double *>(zzb + (size_t)e * M * 8 + t * 8);
-                    double A = exp_glibc_wide(*reinterpret_cast<const double *>(sb + (size_t)(j * M + nn) * 8) - *z, etab);
-                    const int b = bsb[j * M + nn] ^ bbb[e * M + t];
+#pragma unroll 1
+                for (int x = 0; x < cw; ++x) {
+                    const typename BpPlan<C>::Edge ed = P.edge[wave][q][x];
+                    int nn = t - ed.rot; if (nn < 0) nn += M;                         // rotate by m - circ (:1847)
+                    double *z = reinterpret_cast<double *>(zzb + ed.zoff + t * 8);
+                    double A = exp_glibc_wide(*reinterpret_cast<const double *>(sb + (size_t)(ed.jm + nn) * 8) - *z, etab);
+                    const int b = bsb[ed.jm + nn] ^ bbb[ed.boff + t];
                     A = (double)(1 - 2 * b) * log_glibc_t((1 + A) / (1 - A), ltab);
                     const double zn = at_least(at_most(A, 19.07), -19.07);
                     *z = zn;
                     soft += zn;
-                });
+                }
                 so[q] = soft;
                 hb[k * M + t] = soft < 0;
             }
         });
         __syncthreads();
-        fail = vote(syndrome_fail(false));                                          // :1869-1893 (array cleared at :1788)
+        fail = vote(syndrome_fail(false, ln));                                          // :1869-1893 (array cleared at :1788)
         iter = iter + 1;
     }
     const int res = fail ? -iter : iter;
@@ -1889,9 +1932,10 @@ __device__ __forceinline__ void bp_body(const SpecArgs &a) {
         pack_hard<N, T>(a.hard + fr * ((N + 31) / 32), threadIdx.x, [&](int v) { return hb[v] != 0; });
     }
     if (a.soft_out) {
-        static_for<0, NH * CH>([&](auto U) {
-            constexpr int u = decltype(U)::value, k = u / CH, ch = u % CH, q = V.col_slot[u];
-            if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) a.soft_out[fr * N + k * M + ch * 64 + lane] = so[q];
+        static_for<0, UMAX>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            int k, t, cw;
+            if (unit(q, k, t, cw)) a.soft_out[fr * N + k * M + t] = so[q];
         });
     }
 }
