@@ -65,6 +65,11 @@ if b:
                 f"**{er['value'] / 1e6:.2f} M frames/s** noise → decode → count on 65 536-frame batches at 2.0 dB; generator alone "
                 f"**{g['samples_per_s'] / 1e9:.1f} G samples/s** = {g['achieved_GBs'] / 1e3:.2f} TB/s of its {g['algorithmic_bytes_per_sample']:.1f} B/sample algorithmic traffic "
                 f"= {g['frac']:.2f} of the HBM roof" + (f" (PMC: {g['traffic'] / g['samples']:.1f} B/sample physical)." if g.get("traffic") else ".")]
+    rk = b.get("exact_replay_ranks") or {}
+    if rk.get("value"):
+        out.append(f"`exact_replay_ranks` (`host.bp_simulation(exact_seed=1)` as a one-process-per-GPU job, here {rk['n_gpus']} rank; the N > 1 lines must repeat these "
+                   f"counters): {rk['value'] / 1e6:.2f} M frames/s, {rk['ms_per_round']:.2f} ms per {rk['frames_per_round']}-frame round, {rk['errored_frames']} errored of "
+                   f"{rk['frames']} frames, generator state CRC {rk['generator_state_crc32']:#010x}.")
 sh = load("exact_replay_shards.json")
 if sh:
     out += ["", "Generation shared out over n logical shards on ONE GPU (`tools/time_shards.py`, ms per 65 536 frames; on one device the work "

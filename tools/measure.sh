@@ -5,6 +5,7 @@ export ROUND_TAG=$TAG
 # the kernel sources), bench.py plain -> ${TAG}_bench.json, bench.py under rocprofv3 --kernel-trace --stats -> kernel stats CSV.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$TAG
+rm -rf gpurun_out/$TAG/trace
 if [ -z "$SKIP_PMC" ]; then   # (the two halves fit one 20-minute gpurun call each: SKIP_PMC=1 runs the second half only)
 rm -rf gpurun_out/pmc2
 bash tools/prof_pmc2.sh > gpurun_out/$TAG/pmc2.log 2>&1 || { tail -20 gpurun_out/$TAG/pmc2.log; exit 1; }
@@ -24,7 +25,10 @@ for k,c in b.get("configs",{}).items():
 print("cpu", b["cpu_baseline"])
 PY
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/trace -- python3 bench.py --no-cpu-baseline > gpurun_out/$TAG/${TAG}_bench_under_rocprof.json 2> gpurun_out/$TAG/trace.err || { tail -5 gpurun_out/$TAG/trace.err; exit 1; }
-find gpurun_out/$TAG/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/$TAG/${TAG}_kernel_stats.csv
+# bench.py starts child processes (abi_multi, exact_replay_ranks), each with its own trace: the main process's is the longest
+ls -S gpurun_out/$TAG/trace/*/*kernel_trace.csv | head -1 | sed 's/kernel_trace/kernel_stats/' | xargs -I{} cp {} gpurun_out/$TAG/${TAG}_kernel_stats.csv
+ls -S gpurun_out/$TAG/trace/*/*kernel_trace.csv | head -1 | xargs -I{} cp {} gpurun_out/$TAG/${TAG}_kernel_trace.csv
+python3 tools/trace_legs.py gpurun_out/$TAG/${TAG}_kernel_trace.csv gpurun_out/$TAG/${TAG}_bench_under_rocprof.json > gpurun_out/$TAG/${TAG}_kernel_trace_legs.txt 2>&1 || true
 head -12 gpurun_out/$TAG/${TAG}_kernel_stats.csv | cut -c1-160
 # the generation shared out over logical shards (one GPU: the device does the work once whatever n)
 timeout -k 10 300 python tools/time_shards.py 65536 > gpurun_out/$TAG/${TAG}_exact_replay_shards.json 2> gpurun_out/$TAG/time_shards.err || { tail -5 gpurun_out/$TAG/time_shards.err; exit 1; }
