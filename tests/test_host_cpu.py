@@ -503,7 +503,7 @@ def test_device_log_algorithm_equals_libm_log_bit_for_bit(tmp_path):
     fn = hdr[hdr.index("__device__ __forceinline__ double log_glibc_t(double x, Tab T) {"):]
     fn = fn[:fn.index("\n}\n") + 3]
     c_fn = (fn.replace("__device__ __forceinline__ double log_glibc_t(double x, Tab T)", "static double log_glibc(double x)").replace("__fma_rn", "fma")
-              .replace("    auto D = [&](int i) { return __longlong_as_double((long long)T[i]); };\n", "")
+              .replace("    auto D = [&](int i) { return __longlong_as_double((long long)kLogData[i]); };\n", "")
               .replace("const ulonglong2 cpair = *reinterpret_cast<const ulonglong2 *>(&T[18 + 2 * i]);", "const struct { unsigned long long x, y; } cpair = {kLogData[18 + 2 * i], kLogData[19 + 2 * i]};")
               .replace("__longlong_as_double((long long)cpair.x)", "asd(cpair.x)").replace("__longlong_as_double((long long)cpair.y)", "asd(cpair.y)")
               .replace("(unsigned long long)__double_as_longlong(", "asu(").replace("__longlong_as_double((long long)iz)", "asd(iz)")
