@@ -28,5 +28,5 @@ LDPC_AOT_DECLARE(lms_spec_appendix_c_m512_kernel, 512, 2)
 LDPC_AOT_DECLARE(sp_spec_appendix_c_m64_kernel, 512, 4)
 LDPC_AOT_DECLARE(bp_spec_appendix_c_m64_kernel, 512, 4)
 LDPC_AOT_DECLARE(asp_spec_appendix_c_m64_kernel, 512, 4)
-LDPC_AOT_DECLARE(tasp_spec_appendix_c_m64_kernel, 64, 1)
-LDPC_AOT_DECLARE(tasp_spec_appendix_c_m126_kernel, 128, 1)
+LDPC_AOT_DECLARE(tasp_spec_appendix_c_m64_kernel, 128, 2)
+LDPC_AOT_DECLARE(tasp_spec_appendix_c_m126_kernel, 256, 2)

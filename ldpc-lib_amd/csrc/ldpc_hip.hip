@@ -135,8 +135,8 @@ const AotInstance kAot[] = {
     {LDPC_HIP_SP_DEC, (const void *)sp_spec_appendix_c_m64_kernel, 64 * ldpc_spec::kSpBodyWaves, "sp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_BP_DEC, (const void *)bp_spec_appendix_c_m64_kernel, 512, "bp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
     {LDPC_HIP_ASP_DEC, (const void *)asp_spec_appendix_c_m64_kernel, 512, "asp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
-    {LDPC_HIP_TASP_DEC, (const void *)tasp_spec_appendix_c_m64_kernel, 64, "tasp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
-    {LDPC_HIP_TASP_DEC, (const void *)tasp_spec_appendix_c_m126_kernel, 128, "tasp_spec_appendix_c_m126_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM126>},
+    {LDPC_HIP_TASP_DEC, (const void *)tasp_spec_appendix_c_m64_kernel, 128, "tasp_spec_appendix_c_m64_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM64>},
+    {LDPC_HIP_TASP_DEC, (const void *)tasp_spec_appendix_c_m126_kernel, 256, "tasp_spec_appendix_c_m126_kernel", &CodeTables::is<ldpc_spec::CodeAppendixCM126>},
 };
 
 }  // namespace
@@ -350,8 +350,12 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
         break;
     }
     case LDPC_HIP_TASP_DEC:
-        p.required = true;  // per-edge state lives in VGPRs of the check lane: code-specialised instances only
-        if (M <= 256 && t.min_rw >= 2 && t.ne <= 144 && soft_lds <= 64 * 1024) { p.body = "tasp_body"; p.threads = 64 * W; p.lds = soft_lds; }
+        p.required = true;  // per-edge state lives in VGPRs of the two lanes of a check: code-specialised instances only
+        {   // 2 M threads per frame; LDS: a-posteriori probabilities + one spare slot per thread + flag words, 16-bit addresses
+            const int th = 64 * ((2 * M + 63) / 64);
+            const size_t lds = sizeof(double) * ((size_t)N + (size_t)th) + 16;
+            if (M <= 256 && t.min_rw >= 2 && t.ne <= 144 && lds <= 64 * 1024) { p.body = "tasp_body"; p.threads = th; p.lds = lds; }
+        }
         break;
     default: break;
     }

@@ -120,7 +120,10 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
     static std::map<std::string, Kernel> &cache = *new std::map<std::string, Kernel>();   // never destroyed: a background compile may outlive main()
     const std::string code = code_struct(rows, nh, M);
     const bool eight_waves = std::string(body) == "sp_body" || std::string(body) == "asp_body" || std::string(body) == "bp_body";  // 8 waves per frame, 2 frames per CU
-    const int threads = eight_waves ? 512 : std::string(body) == "ms_chunk_body" ? 64 : ((M + 63) / 64) * 64;
+    const bool tasp = std::string(body) == "tasp_body";   // two lanes per check; two waves per SIMD while the Z halves + addresses + ~85 temporaries fit 256 registers
+    int tasp_regs = 85;
+    for (const auto &r : rows) tasp_regs += 2 * (((int)r.size() + 1) / 2) + (((int)r.size() + 1) / 2 + 1) / 2;
+    const int threads = eight_waves ? 512 : std::string(body) == "ms_chunk_body" ? 64 : tasp ? ((2 * M + 63) / 64) * 64 : ((M + 63) / 64) * 64;
     const std::string key = std::to_string(device) + "|" + body + "|" + code;
     // the lock covers the process cache only: a compile takes seconds and must not hold up other contexts
     auto lookup = [&]() -> const Kernel * {
@@ -143,7 +146,7 @@ inline const Kernel *get(int device, const char *body, const std::vector<std::ve
     hs << hf.rdbuf();
     const std::string hdr = hs.str();
     const std::string src = "#include \"ldpc_spec.hpp\"\nnamespace {\n" + code +
-                            "}\nextern \"C\" __global__ void __launch_bounds__(" + std::to_string(threads) + (eight_waves ? ", 4" : (std::string(body) == "tasp_body" || std::string(body) == "ms_chunk_body") ? ", 1" : ", 2") + ") spec_jit(const ldpc_spec::SpecArgs a) {\n"
+                            "}\nextern \"C\" __global__ void __launch_bounds__(" + std::to_string(threads) + (eight_waves ? ", 4" : ((tasp && tasp_regs > 256) || std::string(body) == "ms_chunk_body") ? ", 1" : ", 2") + ") spec_jit(const ldpc_spec::SpecArgs a) {\n"
                             "    ldpc_spec::" + body + "<Code>(a);\n}\n";
     // On-disk cache of compiled code objects: LDPC_HIP_CACHE_DIR, default $XDG_CACHE_HOME/ldpc_hip or $HOME/.cache/ldpc_hip,
     // "off" disables it.  The file name is a hash of everything the object depends on -- the generated source, this header's

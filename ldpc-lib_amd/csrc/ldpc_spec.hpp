@@ -1470,108 +1470,136 @@ __device__ __forceinline__ double div_if(double a, double b) {
 // ---------------------------------------------------------------------------------------------------------------
 // TDMP ("turbo-decoding message passing") sum-product in the probability domain -- upstream
 // tdmp_sum_prod_gf2_decod_qc_lm (decoders.cpp:2584-2744, map_bin :2191-2228), decoder id 7, the decoder_type of every
-// shipped scenario file.  Layered like lms_body: block rows are sequential, one frame per workgroup of ceil(M/64)
-// waves, a-posteriori probabilities P(bit=1) in LDS.  The per-edge state Z (one fp64 per edge and check, which the
-// reference keeps in an R x max-row-weight matrix) lives in VGPRs of the check lane -- 2 VGPRs per circulant, so
-// this kernel runs one wave per SIMD (<= 512 VGPRs) and supports liftings up to 256.
-// Two fp64 divisions per edge and iteration.  The channel transform uses exp_glibc (the reference's exp(), bit for bit), so
-// the probabilities, hard decisions and step counts are identical to the CPU reference's.  As upstream, the result is always
-// the hard decision (`decision` is dead, :2737).
+// shipped scenario file.  Layered like lms_body: block rows are sequential, one frame per workgroup, a-posteriori probabilities
+// P(bit=1) in LDS.  The per-edge state Z (one fp64 per edge and check, which the reference keeps in an R x max-row-weight matrix)
+// lives in VGPRs.  Two fp64 divisions per edge and iteration.  The channel transform uses exp_glibc (the reference's exp(), bit for
+// bit), so the probabilities, hard decisions and step counts are identical to the CPU reference's.  As upstream, the result is
+// always the hard decision (`decision` is dead, :2737).
+//
+// TWO lanes per check (round 3).  Rounds 1-2 kept a check's whole Z row in one lane: 224 registers for the example code, one wave
+// per SIMD, nothing to hide the division chains behind (7 cycles per instruction).  Here lanes 2n and 2n+1 share
+// check n of the current block row: lane A owns the row's first ceil(RW/2) edges in ascending order, lane B the others in DESCENDING
+// order (an odd row pads B with a factor 1.0).  In that order map_bin's two running products are the same code on both lanes:
+//   C1[i] = e[i] * C1[i-1]       A: SF[0..] left to right            B: SB[RW-1..] right to left          (:2209-2216)
+//   X     = the partner's last C1 (one DPP swap of neighbouring lanes: SB[LA] for A, SF[LA-1] for B)
+//   C2[i] = e[i] * C2[i+1], C2[L] = X     A: SB[LA-1..1]             B: SF[LA..RW-2]
+//   q[i]  = (1 - C1[i-1] * C2[i+1]) / 2   (i = 0: 1 - C2[1])         every product has upstream's operands, so upstream's bits
+// Half the state per lane (128 registers) and the LDS address of every edge kept in registers, two to a VGPR (they differ
+// between the lanes of a pair, so they cannot be immediates): 242 registers, two waves per SIMD, and the layers of two frames
+// overlap on every SIMD: 19-23 % less time than one lane per check (profiles/r03_tdmp_pair_ab.txt).  Liftings up to 256.
+// LDS: [N] a-posteriori probabilities, one spare slot per thread (what padded edges and idle lanes read and write), flag words.
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 dpp_swap_pair(u32 v) {   // lane 2n <-> lane 2n+1
+    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ double dpp_swap_pair(double v) { return mk(dpp_swap_pair(hi32(v)), dpp_swap_pair(lo32(v))); }
+
 template <class C>
 __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
-    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, W = (M + 63) / 64;
+    constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, TH = ((2 * M + 63) / 64) * 64, LMAX = (C::WMAX + 1) / 2;
     static_assert(RH <= 64, "tasp_body: div_ranged's lower bound on the probabilities assumes column weights <= 64");
+    static_assert((size_t)N * 8 + (size_t)TH * 8 + 16 <= 65536, "tasp_body: 16-bit LDS addresses");
     constexpr double T = 0.0001, TT = 0;                                   // :2597-2598
-    extern __shared__ double lds[];                                         // [N] soft_out, then one flag word
+    extern __shared__ double lds[];
     char *const ldsb = reinterpret_cast<char *>(lds);
-    int *const flag = reinterpret_cast<int *>(ldsb + (size_t)N * 8);
-    const int n = threadIdx.x;
-    const bool valid = (M % 64 == 0) || n < M;
-    const u32 n8 = (u32)(valid ? n : 0) * 8u;
+    int *const flag = reinterpret_cast<int *>(ldsb + (size_t)N * 8 + (size_t)TH * 8);
+    const int t = threadIdx.x, n = t >> 1;
+    const bool isB = (t & 1) != 0, valid = n < M;
+    const u32 spare = (u32)N * 8u + (u32)t * 8u;
     const long long fr = blockIdx.x;
 
-    auto rot = [&](u32 base, auto S) -> u32 {
-        constexpr int c = decltype(S)::value;
-        if constexpr (c == 0) return base;
-        else if constexpr ((M & (M - 1)) == 0) return (base + 8u * (u32)c) & (u32)(8 * M - 1);
-        else { const u32 t = base + 8u * (u32)c, w = t - (u32)(8 * M); return t < w ? t : w; }   // unsigned min: t - 8M wraps when t < 8M (no VCC select)
+    // LDS byte address of local edge k of block row j for this lane, two to a register
+    u32 pk[RH][(LMAX + 1) / 2];
+    static_for<0, RH>([&](auto J) {
+        constexpr int j = decltype(J)::value, RW = C::RW[j], L = (RW + 1) / 2, LB = RW / 2;
+        static_assert(RW >= 2, "tasp_body: map_bin needs at least two edges per check");
+        static_for<0, (LMAX + 1) / 2>([&](auto H) { pk[j][decltype(H)::value] = spare | (spare << 16); });
+        static_for<0, L>([&](auto K) {
+            constexpr int k = decltype(K)::value, sA = k, sB = k < LB ? RW - 1 - k : 0;
+            int nA = n + C::SH[j][sA]; if (nA >= M) nA -= M;
+            int nB = n + C::SH[j][sB]; if (nB >= M) nB -= M;
+            const u32 adA = (u32)(C::COL[j][sA] * M + nA) * 8u, adB = k < LB ? (u32)(C::COL[j][sB] * M + nB) * 8u : spare;
+            const u32 ad = valid ? (isB ? adB : adA) : spare;
+            if constexpr (k % 2 == 0) pk[j][k / 2] = (pk[j][k / 2] & 0xffff0000u) | ad;
+            else pk[j][k / 2] = (pk[j][k / 2] & 0x0000ffffu) | (ad << 16);
+        });
+    });
+    auto adr = [&](auto J, auto K) -> u32 {
+        constexpr int j = decltype(J)::value, k = decltype(K)::value;
+        if constexpr (k % 2 == 0) return pk[j][k / 2] & 0xffffu;
+        else return pk[j][k / 2] >> 16;
     };
+    // true for the one padded slot of an odd row on the B lane (and only there)
+    auto padded = [&](auto J, auto K) -> bool {
+        constexpr int j = decltype(J)::value, k = decltype(K)::value;
+        if constexpr (k >= C::RW[j] / 2) return isB; else return false;
+    };
+
     FrameVote fvote;
-    if constexpr (W > 1) fvote.init(flag);
-    auto vote = [&](bool fail) -> bool {
-        if constexpr (W == 1) return __ballot(fail) != 0ull;
-        else return fvote(fail);
-    };
+    fvote.init(flag);
     auto syndrome_fail = [&]() -> bool {                                    // check_syndrome_thr :2274-2306, thr 0.5
         bool f = false;
         static_for<0, RH>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            u32 sy = 0, nb = n8;
-            asm volatile("" : "+v"(nb));
-            static_for<0, C::RW[j]>([&](auto S) {
-                constexpr int s = decltype(S)::value;
-                sy ^= (u32)(*reinterpret_cast<const double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M)) > 0.5);
+            constexpr int j = decltype(J)::value, L = (C::RW[j] + 1) / 2;
+            u32 sy = 0;
+            static_for<0, L>([&](auto K) {
+                const bool one = *reinterpret_cast<const double *>(ldsb + adr(J, K)) > 0.5;
+                sy ^= (u32)(one && !padded(J, K));
             });
+            sy ^= dpp_swap_pair(sy);
             f |= sy != 0;
         });
         return valid && f;
     };
 
-    if (valid) {
-        static_for<0, NH>([&](auto K) {                                     // :2611-2618
-            constexpr int k = decltype(K)::value;
-            const double x = a.llr[fr * N + k * M + n] * 0.5;
-            const double y = at_least(at_most(x, 20.0), -20.0);
-            const double e0 = exp_glibc(y), e1 = exp_glibc(-y);
-            *reinterpret_cast<double *>(ldsb + n8 + k * (8 * M)) = e1 / (e0 + e1);
-        });
+    for (int v = t; v < N; v += TH) {                                       // :2611-2618
+        const double x = a.llr[fr * N + v] * 0.5;
+        const double y = at_least(at_most(x, 20.0), -20.0);
+        const double e0 = exp_glibc(y), e1 = exp_glibc(-y);
+        lds[v] = e1 / (e0 + e1);
     }
-    double Z[RH][C::WMAX];
+    *reinterpret_cast<double *>(ldsb + spare) = 0.5;
+    double Z[RH][LMAX];
     static_for<0, RH>([&](auto J) {
-        static_for<0, C::RW[decltype(J)::value]>([&](auto S) { Z[decltype(J)::value][decltype(S)::value] = 0.5; });  // :2637
+        static_for<0, (C::RW[decltype(J)::value] + 1) / 2>([&](auto K) { Z[decltype(J)::value][decltype(K)::value] = 0.5; });  // :2637
     });
-    if constexpr (W > 1) __syncthreads();
+    __syncthreads();
 
     int res = 0;
-    bool fail = vote(syndrome_fail());                                      // :2653-2660: already a codeword -> 0
+    bool fail = fvote(syndrome_fail());                                     // :2653-2660: already a codeword -> 0
     int steps = 0;
     while (fail && steps < a.maxiter) {
         static_for<0, RH>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            constexpr int RW = C::RW[j];
-            static_assert(RW >= 2, "tasp_body: map_bin needs at least two edges per check");
-            u32 nb = n8;
-            asm volatile("" : "+v"(nb));
-            double y[RW], q[RW], P[RW], SF[RW], SB[RW];
-            static_for<0, RW>([&](auto S) {
-                constexpr int s = decltype(S)::value;
-                const double x = *reinterpret_cast<const double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M));
-                const double aa = Z[j][s];
+            constexpr int j = decltype(J)::value, RW = C::RW[j], L = (RW + 1) / 2;
+            static_for<0, (L + 1) / 2>([&](auto H) { u32 w = pk[j][decltype(H)::value]; asm volatile("" : "+v"(w)); pk[j][decltype(H)::value] = w; });   // the unpacked addresses are per-layer values, not 64 more live registers
+            double y[L], e[L], C1[L], C2[L + 1], q[L];
+            static_for<0, L>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                const double x = *reinterpret_cast<const double *>(ldsb + adr(J, K));
+                const double aa = Z[j][k];
                 double v = div_ranged(x * (1.0 - aa), aa + x - 2.0 * aa * x);   // :2686 rho = gamma - lambda; the denominator is >= min(aa, 1 - aa) >= 1e-4
                 v = at_most(at_least(v, TT), 1 - TT);                        // :2694-2695
-                y[s] = v;
-                P[s] = 1 - 2 * v;                                            // map_bin :2206
+                y[k] = v;
+                const double p = 1 - 2 * v;                                  // map_bin :2206
+                e[k] = padded(J, K) ? 1.0 : p;
             });
-            SF[0] = P[0];                                                    // :2209-2216
-            static_for<1, RW - 1>([&](auto I) { constexpr int i = decltype(I)::value; SF[i] = P[i] * SF[i - 1]; });
-            SB[RW - 1] = P[RW - 1];
-            static_for<0, RW - 2>([&](auto I) { constexpr int i = RW - 2 - decltype(I)::value; SB[i] = P[i] * SB[i + 1]; });
-            q[0] = (1 - SB[1]) / 2;                                          // :2219-2227
-            static_for<1, RW - 1>([&](auto I) { constexpr int i = decltype(I)::value; q[i] = (1 - SF[i - 1] * SB[i + 1]) / 2; });
-            q[RW - 1] = (1 - SF[RW - 2]) / 2;
-            static_for<0, RW>([&](auto S) {
-                constexpr int s = decltype(S)::value;
-                double v = q[s];
+            C1[0] = e[0];
+            static_for<1, L>([&](auto I) { constexpr int i = decltype(I)::value; C1[i] = e[i] * C1[i - 1]; });
+            C2[L] = dpp_swap_pair(C1[L - 1]);
+            static_for<0, L - 1>([&](auto I) { constexpr int i = L - 1 - decltype(I)::value; C2[i] = e[i] * C2[i + 1]; });
+            q[0] = (1 - C2[1]) / 2;                                          // :2219-2227
+            static_for<1, L>([&](auto I) { constexpr int i = decltype(I)::value; q[i] = (1 - C1[i - 1] * C2[i + 1]) / 2; });
+            static_for<0, L>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                double v = q[k];
                 v = at_most(at_least(v, T), 1.0 - T);                        // :2703-2704
-                Z[j][s] = v;
-                const double g = div_ranged(y[s] * v, 1.0 - y[s] - v + 2 * y[s] * v);  // :2716 gamma = rho + lambda; denominator >= min(v, 1 - v) >= 1e-4
-                if (valid) *reinterpret_cast<double *>(ldsb + rot(nb, IC<C::SH[j][s]>{}) + C::COL[j][s] * (8 * M)) = g;
+                Z[j][k] = v;
+                const double g = div_ranged(y[k] * v, 1.0 - y[k] - v + 2 * y[k] * v);  // :2716 gamma = rho + lambda; denominator >= min(v, 1 - v) >= 1e-4
+                *reinterpret_cast<double *>(ldsb + adr(J, K)) = g;
             });
-            if constexpr (W > 1) __syncthreads();
-            else __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
         });
-        fail = vote(syndrome_fail());                                        // :2723 (only the value after the last layer counts)
+        fail = fvote(syndrome_fail());                                       // :2723 (only the value after the last layer counts)
         steps = steps + 1;
     }
     res = fail ? -steps : steps;                                             // :2740-2743 (0 when the input was a codeword)
@@ -1579,13 +1607,10 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
     if (threadIdx.x == 0 && a.iters) a.iters[fr] = res;
     if (a.hard) {
         constexpr int HW = (N + 31) / 32;
-        pack_hard<N, W * 64>(a.hard + fr * HW, threadIdx.x, [&](int v) { return *reinterpret_cast<const double *>(ldsb + (size_t)v * 8) > 0.5; });
+        pack_hard<N, TH>(a.hard + fr * HW, threadIdx.x, [&](int v) { return lds[v] > 0.5; });
     }
-    if (a.soft_out && valid) {
-        static_for<0, NH>([&](auto K) {
-            constexpr int k = decltype(K)::value;
-            a.soft_out[fr * N + k * M + n] = *reinterpret_cast<const double *>(ldsb + n8 + k * (8 * M));
-        });
+    if (a.soft_out) {
+        for (int v = t; v < N; v += TH) a.soft_out[fr * N + v] = lds[v];
     }
 }
 

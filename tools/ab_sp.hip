@@ -22,7 +22,9 @@
 #define AB_BODY sp_body
 #endif
 using ldpc_spec::SpecArgs;
-#ifdef AB_IS_SP
+#if defined(AB_THREADS)
+constexpr int kThreads = AB_THREADS;   // e.g. -DAB_BODY=tasp_body -DAB_THREADS=64 -DAB_OCC=1 / -DAB_BODY=tasp_pair_body -DAB_THREADS=128 -DAB_OCC=2
+#elif defined(AB_IS_SP)
 constexpr int kThreads = ldpc_spec::kSpBodyWaves * 64;
 #else
 constexpr int kThreads = ldpc_spec::kSpWaves * 64;
@@ -50,7 +52,7 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(d_llr + (size_t)f * N, h.data(), sizeof(double) * (size_t)std::min(distinct, B - f) * N, hipMemcpyHostToDevice));
     CK(hipFuncSetAttribute((const void *)k_sp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SpecArgs a{};
-    a.llr = d_llr; a.hard = d_hard; a.iters = d_it; a.maxiter = 50; a.alpha = 0.8; a.nframes = B;
+    a.llr = d_llr; a.hard = d_hard; a.iters = d_it; a.maxiter = argc > 5 ? atoi(argv[5]) : 50; a.alpha = 0.8; a.nframes = B;
     void *args[] = {&a};
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
