@@ -1477,11 +1477,11 @@ __device__ __forceinline__ double div_if(double a, double b) {
 // always the hard decision (`decision` is dead, :2737).
 //
 // TWO lanes per check (round 3).  Rounds 1-2 kept a check's whole Z row in one lane: 224 registers for the example code, one wave
-// per SIMD, nothing to hide the division chains behind (7 cycles per instruction).  Here lanes 2n and 2n+1 share
+// per SIMD, nothing to hide the division chains behind (7 cycles per instruction).  Here two lanes (l and l + 32 of a wave) share
 // check n of the current block row: lane A owns the row's first ceil(RW/2) edges in ascending order, lane B the others in DESCENDING
 // order (an odd row pads B with a factor 1.0).  In that order map_bin's two running products are the same code on both lanes:
 //   C1[i] = e[i] * C1[i-1]       A: SF[0..] left to right            B: SB[RW-1..] right to left          (:2209-2216)
-//   X     = the partner's last C1 (one DPP swap of neighbouring lanes: SB[LA] for A, SF[LA-1] for B)
+//   X     = the partner's last C1 (one swap of the wave's halves: SB[LA] for A, SF[LA-1] for B)
 //   C2[i] = e[i] * C2[i+1], C2[L] = X     A: SB[LA-1..1]             B: SF[LA..RW-2]
 //   q[i]  = (1 - C1[i-1] * C2[i+1]) / 2   (i = 0: 1 - C2[1])         every product has upstream's operands, so upstream's bits
 // Half the state per lane (128 registers) and the LDS address of every edge kept in registers, two to a VGPR (they differ
@@ -1489,10 +1489,11 @@ __device__ __forceinline__ double div_if(double a, double b) {
 // overlap on every SIMD: 19-23 % less time than one lane per check (profiles/r03_tdmp_pair_ab.txt).  Liftings up to 256.
 // LDS: [N] a-posteriori probabilities, one spare slot per thread (what padded edges and idle lanes read and write), flag words.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 dpp_swap_pair(u32 v) {   // lane 2n <-> lane 2n+1
-    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+__device__ __forceinline__ u32 swap_halves(u32 v, bool upper) {   // lane l <-> lane l ^ 32 (gfx950: v_permlane32_swap_b32 + one select)
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // r[0]: the lower half's values in both halves, r[1]: the upper half's
+    return upper ? r[0] : r[1];
 }
-__device__ __forceinline__ double dpp_swap_pair(double v) { return mk(dpp_swap_pair(hi32(v)), dpp_swap_pair(lo32(v))); }
+__device__ __forceinline__ double swap_halves(double v, bool upper) { return mk(swap_halves(hi32(v), upper), swap_halves(lo32(v), upper)); }
 
 template <class C>
 __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
@@ -1503,8 +1504,11 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
     extern __shared__ double lds[];
     char *const ldsb = reinterpret_cast<char *>(lds);
     int *const flag = reinterpret_cast<int *>(ldsb + (size_t)N * 8 + (size_t)TH * 8);
-    const int t = threadIdx.x, n = t >> 1;
-    const bool isB = (t & 1) != 0, valid = n < M;
+    // lanes 0-31 of a wave are the A halves of 32 consecutive checks, lanes 32-63 the B halves of the same checks: every half-wave
+    // then reads and writes 32 consecutive doubles of ONE block column (A and B lanes interleaved hit two columns per half-wave and
+    // conflict in about half of the banks: 454 M conflict cycles per launch of the shipped scenario against 70 M)
+    const int t = threadIdx.x, n = (t >> 6) * 32 + (t & 31);
+    const bool isB = (t & 32) != 0, valid = n < M;
     const u32 spare = (u32)N * 8u + (u32)t * 8u;
     const long long fr = blockIdx.x;
 
@@ -1546,7 +1550,7 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
                 const bool one = *reinterpret_cast<const double *>(ldsb + adr(J, K)) > 0.5;
                 sy ^= (u32)(one && !padded(J, K));
             });
-            sy ^= dpp_swap_pair(sy);
+            sy ^= swap_halves(sy, isB);
             f |= sy != 0;
         });
         return valid && f;
@@ -1585,7 +1589,7 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
             });
             C1[0] = e[0];
             static_for<1, L>([&](auto I) { constexpr int i = decltype(I)::value; C1[i] = e[i] * C1[i - 1]; });
-            C2[L] = dpp_swap_pair(C1[L - 1]);
+            C2[L] = swap_halves(C1[L - 1], isB);
             static_for<0, L - 1>([&](auto I) { constexpr int i = L - 1 - decltype(I)::value; C2[i] = e[i] * C2[i + 1]; });
             q[0] = (1 - C2[1]) / 2;                                          // :2219-2227
             static_for<1, L>([&](auto I) { constexpr int i = decltype(I)::value; q[i] = (1 - C1[i - 1] * C2[i + 1]) / 2; });
