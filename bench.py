@@ -317,13 +317,22 @@ def abi_multi_leg(n, steps, warmup, frames):
         }
 
 
+def clean_env():
+    """this process's environment without a launcher's rendezvous variables: a child that starts its own torch.distributed job must not
+    inherit them -- with TORCHELASTIC_USE_AGENT_STORE=True (set by torch.distributed.run) rank 0 would not host the store and every
+    rank of the child job would wait for a server that does not exist"""
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE",
+            "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE")
+    env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
 def run_abi_multi_child(args, timeout=900, leg="abi_multi"):
     """the abi_multi (or exact_ranks) leg in a fresh child process (this one may hold a torch.distributed rank's GPU state, or -- the
     launcher -- must never touch the GPU); returns its JSON or {"error": ...}"""
     import subprocess
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
-                                                           "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env = clean_env()
     cmd = [sys.executable, os.path.abspath(__file__), "--leg", leg, "--gpus", str(args.gpus), "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--frames", str(args.frames), "--backend", args.backend]
     try:
@@ -420,9 +429,8 @@ def exact_ranks_leg(args, timeout=420):
            "--backend", args.backend]
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+        env = dict(clean_env(), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
     deadline, failed = time.time() + timeout, None
     while failed is None and any(p.poll() is None for p in procs):
@@ -457,9 +465,8 @@ def launch_ranks(args):
         cmd.append("--no-extras")
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+        env = dict(clean_env(), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
     deadline = time.time() + float(os.environ.get("LDPC_BENCH_RANK_TIMEOUT", "1500"))
     failed = None

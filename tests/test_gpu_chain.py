@@ -467,6 +467,8 @@ def test_bench_exact_ranks_leg_is_independent_of_the_rank_count(L):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    # as if called from a rank that torch.distributed.run started: the leg's own job must not inherit that launcher's rendezvous
+    env.update(TORCHELASTIC_USE_AGENT_STORE="True", TORCHELASTIC_RUN_ID="outer", GROUP_RANK="0")
     lines = {}
     for n in (1, 3):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--leg", "exact_ranks", "--gpus", str(n), "--steps", "4"], env=env,

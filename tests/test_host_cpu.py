@@ -526,3 +526,20 @@ def test_device_log_algorithm_equals_libm_log_bit_for_bit(tmp_path):
     (tmp_path / "l.c").write_text(src)
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", str(tmp_path / "l.c"), "-o", str(tmp_path / "l"), "-lm"])
     assert subprocess.check_output([str(tmp_path / "l")], text=True).strip() == "0"
+
+
+def test_bench_children_do_not_inherit_a_launchers_rendezvous(monkeypatch):
+    """bench.py starts jobs of its own (the ranks of `--gpus N`, the abi_multi and exact_replay_ranks legs) from inside a rank that
+    torch.distributed.run started: with the launcher's TORCHELASTIC_USE_AGENT_STORE=True in the child's environment its rank 0 would
+    not host the rendezvous store and the child job would hang (seen on the GPU box, round 3)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for k, v in {"RANK": "3", "LOCAL_RANK": "3", "WORLD_SIZE": "8", "MASTER_ADDR": "10.0.0.1", "MASTER_PORT": "29500", "GROUP_RANK": "0",
+                 "ROLE_RANK": "3", "ROLE_NAME": "default", "LOCAL_WORLD_SIZE": "8", "ROLE_WORLD_SIZE": "8", "GROUP_WORLD_SIZE": "1",
+                 "TORCHELASTIC_USE_AGENT_STORE": "True", "TORCHELASTIC_RUN_ID": "x", "TORCHELASTIC_RESTART_COUNT": "0",
+                 "TORCHELASTIC_MAX_RESTARTS": "0", "LDPC_HIP_CACHE_DIR": "/tmp/keep"}.items():
+        monkeypatch.setenv(k, v)
+    env = bench.clean_env()
+    assert not [k for k in env if k.startswith("TORCHELASTIC_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                       "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE")]
+    assert env["LDPC_HIP_CACHE_DIR"] == "/tmp/keep" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "PATH" in env
