@@ -1260,6 +1260,34 @@ __device__ __forceinline__ void lms_small_body(const SpecArgs &a) {
 // other operation is exact and in the reference's order: hard decisions, iteration counts AND the a-posteriori ratios are
 // identical to the CPU reference's.
 // ---------------------------------------------------------------------------------------------------------------
+// a / b for operands whose range is known: the instruction sequence the compiler emits for an fp64 division is
+//   v_div_scale (x2), v_rcp_f64, two Newton steps, q = a*r, e = fma(-b, q, a), v_div_fmas, v_div_fixup;
+// v_div_scale / v_div_fmas / v_div_fixup only act when the denominator is zero, an operand is infinite / NaN / denormal, the
+// numerator is below 2^-969, or the exponents differ by 768 or more (ISA: V_DIV_SCALE_F64) -- otherwise they pass their input
+// through and the result is fma(e, r, q).  The probability-domain decoders divide quantities that are bounded away from all of
+// that by construction: messages are clamped to [1e-4, 1 - 1e-4] (TDMP) resp. [1e-6, 1 - 1e-6] (ASP), channel priors lie in
+// [4.2e-18, 1 - 4.2e-18] (LLR / 2 clamped to +-20), so a posterior or extrinsic probability is >= 4.2e-18 * clamp^(column weight):
+// >= 4e-274 for TDMP (column weight <= block rows <= 64) and >= 4e-258 for ASP with column weight <= 40 -- both far above
+// 2^-969 = 2e-292 -- and every denominator is >= the clamp bound (e.g. aa + x - 2 aa x >= min(aa, 1 - aa)) and <= 1e7.  A numerator
+// may be exactly 0 (1 - sov): 0 * r = 0, e = 0, result +0 as with the full sequence.  So the three instructions are dropped: the
+// SAME eight remaining instructions, hence the same bits, 27 % fewer instructions per division.  ASP columns heavier than 40
+// keep the compiler's division (div_if).
+__device__ __forceinline__ double div_ranged(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double f = __fma_rn(-b, r, 1.0);
+    r = __fma_rn(r, f, r);
+    f = __fma_rn(-b, r, 1.0);
+    r = __fma_rn(r, f, r);
+    const double q = a * r;
+    const double e = __fma_rn(-b, q, a);
+    return __fma_rn(e, r, q);
+}
+template <bool RANGED>
+__device__ __forceinline__ double div_if(double a, double b) {
+    if constexpr (RANGED) return div_ranged(a, b);
+    else return a / b;
+}
+
 #ifndef LDPC_SP_WAVES
 #define LDPC_SP_WAVES 8           // (macros: tools/ab_sp.hip builds the variants)
 #endif
@@ -1312,6 +1340,15 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
     constexpr SpView<C, kSpBodyWaves> V{};
     constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, R = RH * M, CH = (M + 63) / 64, T = kSpBodyWaves * 64;
     constexpr int NE = V.ne, UMAX = V.units_max;
+    // The three divisions per edge and iteration without the scaling / fix-up instructions (div_ranged) for row weights <= 12.  Ranges:
+    // messages after the clamp of :2120 lie in [-5.2e-9, 1.9e8], positive ones are >= 2^-54 (they are (1+a)/(1-a) of an a >= -1 + ulp);
+    // AA = exp(llr) * (product of <= RH of them) is finite, |AA - 1| is 0 or >= 2^-53, |AA + 1| likewise, so z = (AA-1)/(AA+1) has
+    // 2^-54 <= |z| <= 2^54 or is 0; a row product s of <= 12 of them stays inside 2^+-650 -- no operand is denormal, no numerator below
+    // 2^-969, no exponent difference >= 768.  What is left are exact zeros and the poles: 0 / 0 (z = 0 is a factor of its own row
+    // product) is NaN either way; x / 0 with x != 0 is +-inf with the full sequence and NaN without it, and so is what follows from it --
+    // but every such value ends in the clamp of :2120, where mind() / maxd() send NaN and +inf alike to 1.9e8 and -inf cannot arise
+    // from (1+A)/(1-A) without passing through NaN first.  Heavier rows keep the compiler's division.
+    constexpr bool RD = C::WMAX <= 12;
     extern __shared__ double lds[];
     char *const zzb = reinterpret_cast<char *>(lds);                        // ZZ[e][t] at e*M*8 + t*8
     char *const sb = zzb + (size_t)NE * M * 8;                              // s[j][n]
@@ -1381,7 +1418,7 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
                     constexpr int x = decltype(X)::value;
                     double AA = prefix;                                               // :2027-2041, ascending rows
                     static_for<x + 1, CW>([&](auto W2) { AA *= zo[decltype(W2)::value]; });
-                    *reinterpret_cast<double *>(zzb + (size_t)V.ce[k][x] * M * 8 + t8) = (AA - 1) / (AA + 1);  // :2044
+                    *reinterpret_cast<double *>(zzb + (size_t)V.ce[k][x] * M * 8 + t8) = div_if<RD>(AA - 1, AA + 1);  // :2044
                     prefix *= zo[x];
                 });
             }
@@ -1412,8 +1449,8 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
                     constexpr int x = decltype(X)::value;
                     int nn = t - V.cc[k][x]; if (nn < 0) nn += M;                    // rotate by M-circ (:2113)
                     double *zp = reinterpret_cast<double *>(zzb + (size_t)V.ce[k][x] * M * 8 + t * 8);
-                    double A = *reinterpret_cast<const double *>(sb + (size_t)(V.cj[k][x] * M + nn) * 8) / *zp;
-                    A = (1 + A) / (1 - A);
+                    double A = div_if<RD>(*reinterpret_cast<const double *>(sb + (size_t)(V.cj[k][x] * M + nn) * 8), *zp);
+                    A = div_if<RD>(1 + A, 1 - A);
                     A = at_least(at_most(A, 1.9e+8), -5.2e-9);                        // :2120 (negative lower clamp is upstream's)
                     *zp = A;
                     soft *= A;
@@ -1437,34 +1474,6 @@ __device__ __forceinline__ void sp_body(const SpecArgs &a) {
             if (wave == V.col_wave[u] && lane_ok(IC<ch>{})) a.soft_out[fr * N + k * M + ch * 64 + lane] = sf[q];
         });
     }
-}
-
-// a / b for operands whose range is known: the instruction sequence the compiler emits for an fp64 division is
-//   v_div_scale (x2), v_rcp_f64, two Newton steps, q = a*r, e = fma(-b, q, a), v_div_fmas, v_div_fixup;
-// v_div_scale / v_div_fmas / v_div_fixup only act when the denominator is zero, an operand is infinite / NaN / denormal, the
-// numerator is below 2^-969, or the exponents differ by 768 or more (ISA: V_DIV_SCALE_F64) -- otherwise they pass their input
-// through and the result is fma(e, r, q).  The probability-domain decoders divide quantities that are bounded away from all of
-// that by construction: messages are clamped to [1e-4, 1 - 1e-4] (TDMP) resp. [1e-6, 1 - 1e-6] (ASP), channel priors lie in
-// [4.2e-18, 1 - 4.2e-18] (LLR / 2 clamped to +-20), so a posterior or extrinsic probability is >= 4.2e-18 * clamp^(column weight):
-// >= 4e-274 for TDMP (column weight <= block rows <= 64) and >= 4e-258 for ASP with column weight <= 40 -- both far above
-// 2^-969 = 2e-292 -- and every denominator is >= the clamp bound (e.g. aa + x - 2 aa x >= min(aa, 1 - aa)) and <= 1e7.  A numerator
-// may be exactly 0 (1 - sov): 0 * r = 0, e = 0, result +0 as with the full sequence.  So the three instructions are dropped: the
-// SAME eight remaining instructions, hence the same bits, 27 % fewer instructions per division.  ASP columns heavier than 40
-// keep the compiler's division (div_if).
-__device__ __forceinline__ double div_ranged(double a, double b) {
-    double r = __builtin_amdgcn_rcp(b);
-    double f = __fma_rn(-b, r, 1.0);
-    r = __fma_rn(r, f, r);
-    f = __fma_rn(-b, r, 1.0);
-    r = __fma_rn(r, f, r);
-    const double q = a * r;
-    const double e = __fma_rn(-b, q, a);
-    return __fma_rn(e, r, q);
-}
-template <bool RANGED>
-__device__ __forceinline__ double div_if(double a, double b) {
-    if constexpr (RANGED) return div_ranged(a, b);
-    else return a / b;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
