@@ -133,6 +133,7 @@ class MtFrameSource:
             self.dec.mt_llr(snr, frames, modulation=mod, punctured_blocks=punct, skip=True)
 
     group = None   # torch.distributed group of the job (bp_simulation sets it)
+    share_single = False   # tests: run the exchange protocol in a job of ONE rank too (RCCL collectives on the one-GPU box)
 
     def round(self, total, lo, hi):
         """records of frames [lo, hi) of the next `total` frames.  In a torch.distributed job with equal contiguous slices the ranks
@@ -145,7 +146,8 @@ class MtFrameSource:
         dev = torch.device("cuda", self.dec.device)   # device tensors: the record exchange may run over RCCL
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank(group) if world > 1 else 0
-        shared = (world > 1 and self.share_tape and total <= 65536 and total * self.n <= (1 << 27)
+        in_job = dist.is_available() and dist.is_initialized()
+        shared = ((world > 1 or (self.share_single and in_job)) and self.share_tape and total <= 65536 and total * self.n <= (1 << 27)
                   and lo == total * rank // world and hi == total * (rank + 1) // world)
         if shared:
             host = torch.device("cpu")

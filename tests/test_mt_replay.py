@@ -537,3 +537,48 @@ def test_shard_protocol_through_the_c_abi(L, torch, dec_id, M, snr, n, rounds, m
     finally:
         for d in ranks:
             d.close()
+
+
+_NCCL_ONE_RANK_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import ldpc_lib_amd
+from ldpc_lib_amd import host
+from ldpc_testlib import load_base_matrix, relift
+from test_mt_replay import _EXACT_CASES, raw_after
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+out = []
+for dec_id, M, snr, maxit, n_fe, n_exp, ref, seed in _EXACT_CASES[:2]:
+    H = relift(load_base_matrix(), M)
+    src = host.MtFrameSource(H, M, dec_id, maxit, snr, 0, 0, seed, 0, 0.8)
+    src.share_single = True
+    ber, fer, st = ldpc_lib_amd.bp_simulation(H, M, maxit, n_fe, n_exp, snr, ref, decoder_type=dec_id, batch=1500, return_state=True, source=src)
+    src.close()
+    out.append([st["nse"], st["nde"], st["nue"], st["experiment"], st["sum_abs_iters"], ber.hex(), fer.hex(), int(raw_after(*st["generator"], 0, 1)[0]),
+                st["tape_shared_rounds"], st["tape_fallback_rounds"]])
+print("RESULT", json.dumps(out))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_rank_protocol_over_rccl_with_one_rank(L, torch):
+    """the exchanges of the rank-sharded exact replay (all-gather of counts, all-gather of flags, broadcast of the state, all-gather of
+    the records) through torch.distributed's nccl backend = RCCL on DEVICE tensors, in a job of one rank -- what a one-GPU box can run
+    of the path the N > 1 nccl job takes; results against the oracle's sequential loop."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29400 + os.getpid() % 500), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", _NCCL_ONE_RANK_WORKER.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    got = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][0].split(" ", 1)[1])
+    for row, (dec_id, M, snr, maxit, n_fe, n_exp, ref, seed) in zip(got, _EXACT_CASES[:2]):
+        res = _oracle_sim(relift(load_base_matrix(), M), M, dec_id, snr, maxit, n_fe, n_exp, ref, seed)
+        assert row[:5] == [res.nse, res.nde, res.nue, res.experiment, res.sum_abs_iter]
+        assert row[5] == float(res.ber).hex() and row[6] == float(res.fer).hex() and row[7] == res.rng_next
+        assert row[8] > 0 and row[9] == 0, row
