@@ -416,8 +416,7 @@ int ldpc_hip_mt_shard_begin(ldpc_hip_ctx *c, double snr_db, int modulation_type,
     };
     r.cut_lo = cut(rank); r.cut_hi = cut(rank + 1);
     *own_count = 0;
-    r.open = true;
-    if (r.cut_lo >= r.cut_hi) { r.w = MtWindow(); return 0; }   // nothing to own (and then no rows either, or the caller falls back)
+    if (r.cut_lo >= r.cut_hi) { r.w = MtWindow(); r.open = true; return 0; }   // nothing to own (and then no rows either, or the caller falls back)
     const long long a_lo = r.cut_lo - r.pl.margin, a_hi = r.cut_hi + r.pl.margin;
     r.w = mt_window(r.pl, r.pl.pos + 4 * (a_lo < 0 ? 0 : a_lo), r.pl.pos + 4 * (a_hi > r.pl.attempts ? r.pl.attempts : a_hi) + MTN);
     if (int rc = mt_ensure(c, r.w)) return rc;
@@ -427,6 +426,7 @@ int ldpc_hip_mt_shard_begin(ldpc_hip_ctx *c, double snr_db, int modulation_type,
     HIP_TRY(hipMemcpy(cnt, c->mt.d_counters, sizeof cnt, hipMemcpyDeviceToHost));
     r.left = cnt[0]; r.own = cnt[1];
     *own_count = r.own;
+    r.open = true;   // only now: a begin that failed half way leaves no round behind for emit / commit to pick up
     return 0;
 }
 

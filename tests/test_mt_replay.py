@@ -303,6 +303,12 @@ def test_generator_needs_a_state_and_sane_arguments(L, torch):
         assert dec.mt_normal(0).numel() == 0
         info, its = dec.mt_frames(2.0, 50, 0)
         assert info.shape == (0,) and its.shape == (0,)
+        # the rank protocol: nothing to emit or commit without a round, no round from bad arguments -- and none left behind by them
+        for bad in (lambda: dec.mt_shard_emit([0]), lambda: dec.mt_shard_commit(np.zeros(624, dtype=np.uint32), 0, 50, 0),
+                    lambda: dec.mt_shard_begin(2.0, 10, 3, 2), lambda: dec.mt_shard_begin(2.0, 70000, 0, 2), lambda: dec.mt_shard_begin(2.0, 0, 0, 1),
+                    lambda: dec.mt_shard_emit([0, 0])):
+            with pytest.raises(L.LdpcHipError):
+                bad()
 
 
 # ---- the Python harness (ldpc_lib_amd.bp_simulation(exact_seed=...)), one process and two ranks ----------------------------------
