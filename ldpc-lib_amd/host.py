@@ -143,7 +143,8 @@ class MtFrameSource:
         import torch.distributed as dist
         snr, mod, punct, maxit, alpha = self.args
         group = self.group
-        dev = torch.device("cuda", self.dec.device)   # device tensors: the record exchange may run over RCCL
+        # device tensors: the record exchange may run over RCCL (a decoder without a device: the CPU tests' stand-in)
+        dev = torch.device("cuda", self.dec.device) if self.dec.device is not None else torch.device("cpu")
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank(group) if world > 1 else 0
         in_job = dist.is_available() and dist.is_initialized()

@@ -543,3 +543,88 @@ def test_bench_children_do_not_inherit_a_launchers_rendezvous(monkeypatch):
     assert not [k for k in env if k.startswith("TORCHELASTIC_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                                        "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE")]
     assert env["LDPC_HIP_CACHE_DIR"] == "/tmp/keep" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "PATH" in env
+
+
+_RANK_PROTOCOL_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import ldpc_lib_amd
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+
+class FakeDec:
+    # the C-ABI calls MtFrameSource.round() makes, on a tape whose 'generator state' is the number of frames drawn so far; frame f's
+    # record is (f, 1).  script[k] says how round k goes: ("ok",), ("uncovered", r): rank r's window does not cover its rows,
+    # ("nobody",): no rank finds the end state, ("short", d): the round completes only total - d frames
+    device = None
+    def __init__(self, script):
+        self.pos, self.script, self.k, self.log = 0, script, 0, []
+    def mt_shard_begin(self, snr, total, rank, n, modulation=0, punctured_blocks=0):
+        self.cur = (total, rank, n, self.script[self.k]); self.k += 1
+        return (total * (rank + 1) // n - total * rank // n) * 7
+    def mt_shard_emit(self, counts):
+        total, rank, n, how = self.cur
+        assert len(counts) == n and sum(counts) == total * 7
+        fdone = total - how[1] if how[0] == "short" else total
+        st = np.zeros(624, dtype=np.uint32); st[0] = self.pos + fdone
+        found = rank == n - 1 and how[0] != "nobody"
+        covered = not (how[0] == "uncovered" and how[1] == rank)
+        return found, covered, (st if found else np.zeros(624, dtype=np.uint32)), fdone
+    def mt_shard_commit(self, state, fdone, maxit, rows, alpha=0.8):
+        total, rank, n, how = self.cur
+        lo = total * rank // n
+        ids = np.arange(self.pos + lo, self.pos + lo + rows, dtype=np.int32)
+        self.pos = int(state[0]); self.log.append("commit")
+        return ids, np.ones(rows, dtype=np.int32)
+    def mt_shard_abandon(self):
+        self.log.append("abandon")
+    def mt_frames(self, snr, maxit, B, modulation=0, punctured_blocks=0, alpha=0.8, lo=None, hi=None):
+        lo = 0 if lo is None else lo; hi = B if hi is None else hi
+        ids = np.arange(self.pos + lo, self.pos + hi, dtype=np.int32)
+        self.pos += B; self.log.append("frames")
+        return ids, np.ones(hi - lo, dtype=np.int32)
+
+script = [("ok",), ("uncovered", world - 1), ("ok",), ("short", 5), ("nobody",), ("ok",)]
+src = ldpc_lib_amd.MtFrameSource.__new__(ldpc_lib_amd.MtFrameSource)
+src.dec, src.n, src.r, src.args = FakeDec(script), 2048, 1024, (2.0, 0, 0, 50, 0.8)
+src.share_tape, src.shared_rounds, src.fallback_rounds = True, 0, 0
+seen, first = [], 0
+for total in (30, 31, 64, 50, 33, 9 * world):
+    lo, hi = total * rank // world, total * (rank + 1) // world
+    info, its = src.round(total, lo, hi)
+    rows = torch.tensor([len(info)]); allrows = [torch.zeros_like(rows) for _ in range(world)]
+    dist.all_gather(allrows, rows)
+    pad = torch.full((total,), -1, dtype=torch.int32); pad[:len(info)] = info.cpu()
+    got = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(got, pad)
+    ids = np.concatenate([g.numpy()[:int(a)] for g, a in zip(got, allrows)])
+    assert np.array_equal(ids, np.arange(first, first + total)), (total, ids[:8], first)
+    first += total
+    assert src.dec.pos == first
+print("RESULT", rank, json.dumps([src.shared_rounds, src.fallback_rounds, src.dec.log]))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_protocol_of_the_sharded_exact_replay_on_a_scripted_tape(world):
+    """host.MtFrameSource.round() over gloo against a stand-in for the C-ABI calls: a round that goes through, one whose last rank is not
+    covered (every rank must abandon and run the whole tape), a short round (the remainder the plain way, on every rank), one in which
+    nobody finds the end state (fallback again).  Every rank must hand back exactly its slice of consecutive frames and end with the
+    same generator position."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", _RANK_PROTOCOL_WORKER.format(root=ROOT)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for o in outs:
+        shared, fallback, log = json.loads([ln for ln in o.splitlines() if ln.startswith("RESULT")][0].split(" ", 2)[2])
+        assert (shared, fallback) == (4, 2)
+        assert log == ["commit", "abandon", "frames", "commit", "commit", "frames", "abandon", "frames", "commit"]
