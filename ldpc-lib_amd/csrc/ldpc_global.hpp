@@ -15,7 +15,7 @@
 //                      columns all hold exactly two circulants, :2431-2480).
 //   tasp_global_kernel tdmp_sum_prod_gf2_decod_qc_lm  decoders.cpp:2584-2744 (decoder 7, the decoder of upstream's shipped scenarios):
 //                      per-edge lambda / rho / forward / backward products in the workspace instead of VGPRs, so row weight and
-//                      the number of circulants are unbounded (the resident tasp_body holds <= 144 edges in registers).
+//                      the number of circulants are unbounded (the resident tasp_body holds the Z state of ~300 circulants in the registers of two lanes per check).
 // The arithmetic is upstream's, literally (comparisons `< 0`, explicit branches, additions in upstream's order):
 //   ms_global_kernel   min_sum_decod_qc_lm   decoders.cpp:4554-4767.  STATE1 is done from the VARIABLE side (a thread walks its
 //                      column's circulants in ascending block row = upstream's order of additions into soft[], :4633-4667), which

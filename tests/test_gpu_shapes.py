@@ -66,12 +66,13 @@ def _llr(H, M, snr, seed, frames):
 @pytest.mark.parametrize("dec_id,maxiter,snr", [(MS_DEC, 50, 2.2), (LMS_DEC, 50, 1.4), (TASP_DEC, 15, 1.4)])
 def test_thirty_by_sixty_at_lifting_67(L, torch, dec_id, maxiter, snr):
     """The shape of files/input12L.jsonx (rows 30, columns 60, tailbite length 67; information column weights 2 / 3 / 16).
-    Min-sum and layered min-sum run on hiprtc instances of the resident bodies; TDMP sum-product has 206 circulants, more than the
-    144 whose state tasp_body can hold in registers, and runs on the shape-unlimited tier."""
+    All three run on hiprtc instances of the resident bodies.  TDMP sum-product has 206 circulants: more than the 144 whose state one
+    lane per check could hold in registers (rounds 1-2: shape-unlimited tier), but with two lanes per check a lane holds half a row
+    and the resident body takes it at one wave per SIMD."""
     rng = np.random.RandomState(67)
     H = random_qc_code(rng, 30, 60, 67, [2, 3, 3, 16, 2, 3])
     llr = _llr(H, 67, snr, 5, 24)
-    name, it = _check(L, torch, dec_id, H, 67, llr, maxiter)
+    name, it = _check(L, torch, dec_id, H, 67, llr, maxiter, expect_kernel="hiprtc")
     assert (it > 0).any() and (it < 0).any(), it       # both converged and failed frames in the sample
 
 
