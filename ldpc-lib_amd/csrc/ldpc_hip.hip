@@ -351,14 +351,14 @@ SpecPlan plan_spec(int decoder_id, const CodeTables &t) {
     }
     case LDPC_HIP_TASP_DEC:
         p.required = true;  // per-edge state lives in VGPRs of the two lanes of a check: code-specialised instances only
-        {   // 2 M threads per frame; LDS: a-posteriori probabilities + one spare slot per thread + flag words, 16-bit addresses
+        {   // 2 M threads per frame; LDS: a-posteriori probabilities + one spare slot per thread + flag words
             const int th = 64 * ((2 * M + 63) / 64);
             const size_t lds = sizeof(double) * ((size_t)N + (size_t)th) + 16;
             // registers of a lane: its half of every row's Z (2 each), the packed LDS addresses, ~85 temporaries (ldpc_jit.hpp picks one
             // or two waves per SIMD from the same estimate); rounds 1-2 (the whole row in one lane) stopped at 144 circulants
             int regs = 85;
             for (int j = 0; j < t.rh; ++j) { const int L = (t.row_start[j + 1] - t.row_start[j] + 1) / 2; regs += 2 * L + (L + 1) / 2; }
-            if (M <= 256 && t.min_rw >= 2 && t.rh <= 64 && regs <= 480 && lds <= 64 * 1024) { p.body = "tasp_body"; p.threads = th; p.lds = lds; }
+            if (M <= 256 && t.min_rw >= 2 && t.rh <= 64 && regs <= 480 && lds <= kLdsBudget) { p.body = "tasp_body"; p.threads = th; p.lds = lds; }
         }
         break;
     default: break;

@@ -1508,7 +1508,10 @@ template <class C>
 __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
     constexpr int RH = C::RH, NH = C::NH, M = C::M, N = NH * M, TH = ((2 * M + 63) / 64) * 64, LMAX = (C::WMAX + 1) / 2;
     static_assert(RH <= 64, "tasp_body: div_ranged's lower bound on the probabilities assumes column weights <= 64");
-    static_assert((size_t)N * 8 + (size_t)TH * 8 + 16 <= 65536, "tasp_body: 16-bit LDS addresses");
+    // the packed addresses are byte addresses while the LDS image fits 64 KB, else 8-byte word indices (one more shift per access)
+    constexpr bool WIDE = (size_t)N * 8 + (size_t)TH * 8 + 16 > 65536;
+    constexpr int AS = WIDE ? 3 : 0;
+    static_assert(((size_t)N * 8 + (size_t)TH * 8 + 16) >> AS <= 65536, "tasp_body: 16-bit packed LDS addresses");
     constexpr double T = 0.0001, TT = 0;                                   // :2597-2598
     extern __shared__ double lds[];
     char *const ldsb = reinterpret_cast<char *>(lds);
@@ -1526,21 +1529,21 @@ __device__ __forceinline__ void tasp_body(const SpecArgs &a) {
     static_for<0, RH>([&](auto J) {
         constexpr int j = decltype(J)::value, RW = C::RW[j], L = (RW + 1) / 2, LB = RW / 2;
         static_assert(RW >= 2, "tasp_body: map_bin needs at least two edges per check");
-        static_for<0, (LMAX + 1) / 2>([&](auto H) { pk[j][decltype(H)::value] = spare | (spare << 16); });
+        static_for<0, (LMAX + 1) / 2>([&](auto H) { pk[j][decltype(H)::value] = (spare >> AS) | ((spare >> AS) << 16); });
         static_for<0, L>([&](auto K) {
             constexpr int k = decltype(K)::value, sA = k, sB = k < LB ? RW - 1 - k : 0;
             int nA = n + C::SH[j][sA]; if (nA >= M) nA -= M;
             int nB = n + C::SH[j][sB]; if (nB >= M) nB -= M;
             const u32 adA = (u32)(C::COL[j][sA] * M + nA) * 8u, adB = k < LB ? (u32)(C::COL[j][sB] * M + nB) * 8u : spare;
-            const u32 ad = valid ? (isB ? adB : adA) : spare;
+            const u32 ad = (valid ? (isB ? adB : adA) : spare) >> AS;
             if constexpr (k % 2 == 0) pk[j][k / 2] = (pk[j][k / 2] & 0xffff0000u) | ad;
             else pk[j][k / 2] = (pk[j][k / 2] & 0x0000ffffu) | (ad << 16);
         });
     });
     auto adr = [&](auto J, auto K) -> u32 {
         constexpr int j = decltype(J)::value, k = decltype(K)::value;
-        if constexpr (k % 2 == 0) return pk[j][k / 2] & 0xffffu;
-        else return pk[j][k / 2] >> 16;
+        if constexpr (k % 2 == 0) return (pk[j][k / 2] & 0xffffu) << AS;
+        else return (pk[j][k / 2] >> 16) << AS;
     };
     // true for the one padded slot of an odd row on the B lane (and only there)
     auto padded = [&](auto J, auto K) -> bool {

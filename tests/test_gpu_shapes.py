@@ -83,12 +83,13 @@ def test_row_weight_sixteen(L, torch, dec_id):
 
 
 @pytest.mark.parametrize("rh,nh,M,target", [(3, 9, 33, 5), (4, 12, 47, 5), (5, 15, 95, 6), (4, 16, 20, 6), (6, 18, 255, 7), (8, 24, 129, 9), (3, 8, 64, 0),
-                                            (5, 11, 32, 0), (7, 15, 31, 0)])
+                                            (5, 11, 32, 0), (7, 15, 31, 0), (16, 32, 256, 0), (10, 36, 250, 0)])
 def test_tdmp_with_two_lanes_per_check_on_odd_shapes(L, torch, rh, nh, M, target):
     """tasp_body splits every check row over two lanes (first half ascending, second half descending, an odd row padded with a factor
     1.0) and pairs lane l with lane l + 32: rows of even and odd weight (halves of 3 / 2, 3 / 3, 4 / 3, 5 / 4), liftings that
     fill a wave's halves unevenly (33, 47, 95, 129, 255), one that leaves a whole half-wave idle (20, 31) and one that fills it
-    exactly (32, 64); target 0 = random column weights 2 / 3 (rows of mixed weight)."""
+    exactly (32, 64); target 0 = random column weights 2 / 3 (rows of mixed weight).  The last two have LDS images beyond 64 KB
+    (N = 8192 and 9000): the packed 16-bit addresses are then 8-byte word indices."""
     rng = np.random.RandomState(rh * 100 + M)
     H = _rows_of_weight(rng, rh, nh, M, target) if target else random_qc_code(rng, rh, nh, M, [2, 3])
     name, it = _check(L, torch, TASP_DEC, H, M, _llr(H, M, 2.5, 9, 40), 15, expect_kernel="tasp_body")
