@@ -85,19 +85,19 @@ def test_golden_vectors_host_api(L, name):
     (IMS_DEC, 100, (1.5, 2.5), 30, 50),        # hiprtc int8 instance, 28 idle lanes
     (IMS_DEC, 256, (1.8,), 12, 50),            # hiprtc int8 instance, 4 waves per frame
     (IMS_DEC, 512, (1.8,), 6, 50),             # LDS would not hold the doubled arrays: table-driven kernel
-    (TASP_DEC, 64, (1.0, 1.7, 2.5), 120, 15),   # TDMP sum-product, ahead-of-time instance
-    (TASP_DEC, 126, (1.7,), 24, 15),            # the shipped scenario's lifting, 2 waves per frame
-    (TASP_DEC, 40, (2.5,), 60, 30),             # hiprtc instance, 24 idle lanes
-    (TASP_DEC, 200, (1.6,), 10, 15),            # hiprtc instance, 4 waves per frame
-    (ASP_DEC, 64, (1.0, 1.6, 2.2), 120, 30),    # probability-domain flooding sum-product (decoder 2), ahead-of-time instance
+    (TASP_DEC, 64, (1.0, 1.7, 2.5), 600, 15),   # TDMP sum-product, ahead-of-time instance
+    (TASP_DEC, 126, (1.2, 1.7, 2.4), 400, 15),   # the shipped scenario's lifting: 4 waves per frame (two lanes per check), 4 idle lanes
+    (TASP_DEC, 40, (2.5,), 60, 30),             # hiprtc instance, two waves, the second one a quarter full
+    (TASP_DEC, 200, (1.6,), 24, 15),            # hiprtc instance, 7 waves per frame (two lanes per check)
+    (ASP_DEC, 64, (1.0, 1.6, 2.2), 300, 30),    # probability-domain flooding sum-product (decoder 2), ahead-of-time instance
     (ASP_DEC, 128, (1.7,), 20, 25),             # hiprtc instance, two 64-lane chunks per block row/column
     (ASP_DEC, 126, (1.7,), 16, 25),             # the lifting of the shipped scenarios: last chunk 62 lanes
     (ASP_DEC, 20, (3.0,), 60, 30),              # one partly idle chunk
-    (BP_DEC, 64, (1.0, 1.6, 2.2), 120, 30),     # Gallager BP (decoder 0), ahead-of-time instance; failed frames chain into successors
+    (BP_DEC, 64, (1.0, 1.6, 2.2), 300, 30),     # Gallager BP (decoder 0), ahead-of-time instance; failed frames chain into successors
     (BP_DEC, 128, (1.7,), 20, 25),              # hiprtc instance
     (BP_DEC, 126, (1.4, 1.7), 24, 25),          # the lifting of the shipped scenarios; failed frames chain
     (BP_DEC, 9, (2.5,), 80, 30),
-    (SP_DEC, 126, (1.7,), 16, 30),              # code-specialised sum-product for a lifting that is not a multiple of 64
+    (SP_DEC, 126, (1.2, 1.7), 120, 30),          # code-specialised sum-product for a lifting that is not a multiple of 64
 ])
 def test_random_batches_against_oracle(L, torch, dec_id, M, snrs, frames, maxiter):
     H = relift(load_base_matrix(), M)
