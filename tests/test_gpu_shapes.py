@@ -96,6 +96,18 @@ def test_tdmp_with_two_lanes_per_check_on_odd_shapes(L, torch, rh, nh, M, target
     assert (it != 0).any()
 
 
+@pytest.mark.parametrize("dec_id,w,maxiter", [(SP_DEC, 10, 30), (SP_DEC, 12, 30), (SP_DEC, 13, 30), (SP_DEC, 16, 30), (TASP_DEC, 12, 15), (TASP_DEC, 16, 15),
+                                               (ASP_DEC, 12, 30), (ASP_DEC, 16, 30)])
+def test_heavy_rows_in_the_sum_product_family(L, torch, dec_id, w, maxiter):
+    """Row weights the soak does not reach (it stops at 8).  sp_body divides without the scaling / fix-up instructions up to row
+    weight 12 (the range argument is about products of that many messages) and with the compiler's division beyond; TDMP halves of
+    6 and 8 edges per lane; at 2 dB and at 6 dB (saturated messages, the poles of (1+A)/(1-A))."""
+    H = _rows_of_weight(np.random.RandomState(100 + w), 4, 24, 64, w)
+    llr = np.concatenate([_llr(H, 64, 2.0, 7, 24), _llr(H, 64, 6.0, 8, 24)])
+    name, it = _check(L, torch, dec_id, H, 64, llr, maxiter, expect_kernel="hiprtc")
+    assert (it > 0).any()
+
+
 GLOBAL_SHAPES = [
     # what the resident kernels refuse                                   rh  nh   M    weights        snr
     ("lifting 600 > 512",                                                 16, 32, 600, None,          1.6),
